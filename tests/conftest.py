@@ -1,0 +1,46 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Return (tensors, cfg, batch) of tests/golden/<name>.safetensors."""
+    from safetensors import safe_open
+    path = os.path.join(GOLDEN_DIR, f"{name}.safetensors")
+    tensors = {}
+    with safe_open(path, framework="pt", device="cpu") as f:
+        meta = f.metadata()
+        for k in f.keys():
+            tensors[k] = f.get_tensor(k)
+    return tensors, json.loads(meta["config"]), int(meta["batch"])
+
+
+def sub(tensors, prefix):
+    """Entries under `prefix/` with the prefix stripped."""
+    n = len(prefix) + 1
+    return {k[n:]: v for k, v in tensors.items() if k.startswith(prefix + "/")}
+
+
+def noise_keys(tensors):
+    """Parameters whose exact gradient is zero: conv / temb-projection biases that feed a
+    train-mode BatchNorm (the mean subtraction cancels them).  Their computed gradient is
+    rounding noise, ~1e-9 in the golden vectors."""
+    return {k[len("grad/"):] for k in tensors
+            if k.startswith("grad/") and k.endswith((".block1.0.2.bias", ".linear_temb.bias"))}
+
+
+@pytest.fixture(scope="session", params=["t0", "t1", "t0_drop"])
+def golden(request):
+    return (request.param,) + load_golden(request.param)

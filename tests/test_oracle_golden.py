@@ -1,0 +1,114 @@
+"""Pins the CPU restatement (oracle/restatement.py) to the golden vectors that
+oracle/make_golden.py captured from the unmodified reference models/ddpm.py."""
+import torch
+import pytest
+
+from oracle import restatement as R
+from conftest import sub, noise_keys
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def _clone(sd):
+    return {k: v.clone() for k, v in sd.items()}
+
+
+def _masks(g, cfg, prefix=""):
+    if cfg["dropout"] == 0.0:
+        return None
+    return {"Middle.0": g[f"{prefix}dropmask/0"], "Middle.2": g[f"{prefix}dropmask/1"]}
+
+
+def test_state_template_matches_reference_keys(golden):
+    name, g, cfg, B = golden
+    sd = sub(g, "state0")
+    tmpl = R.state_template(cfg)
+    assert list(tmpl) == list(sd) or set(tmpl) == set(sd)
+    for k, (shape, dt) in tmpl.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+        assert sd[k].dtype == dt, k
+
+
+def test_schedule_and_timeembed(golden):
+    name, g, cfg, B = golden
+    n, s = R.diffusion_schedule(g["t"])
+    torch.testing.assert_close(n, g["sched_n"], rtol=0, atol=0)
+    torch.testing.assert_close(s, g["sched_s"], rtol=0, atol=0)
+    torch.testing.assert_close(R.timeembed(n ** 2, cfg["h_dims"][1]), g["timeembed"], rtol=0, atol=0)
+    torch.testing.assert_close(s * g["x0"] + n * g["eps"], g["x_t"], rtol=0, atol=0)
+
+
+def test_forward_eval(golden):
+    name, g, cfg, B = golden
+    sd = _clone(sub(g, "state0"))
+    out = R.unet_forward(sd, cfg, g["x_t"], g["sched_n"] ** 2, training=False)
+    torch.testing.assert_close(out, g["fwd_eval"], **TOL)
+    pred_images = (g["x_t"] - g["sched_n"] * out) / g["sched_s"]
+    torch.testing.assert_close(pred_images, g["denoise_pred_images"], rtol=1e-4, atol=1e-5)
+
+
+def test_loss_grads_bnstats(golden):
+    name, g, cfg, B = golden
+    sd = _clone(sub(g, "state0"))
+    loss, grads = R.loss_and_grads(sd, cfg, g["x0"], g["eps"], g["t"], _masks(g, cfg))
+    torch.testing.assert_close(loss.reshape(1), g["loss"], rtol=1e-6, atol=0)
+    ref = sub(g, "grad")
+    assert set(ref) == set(grads)
+    for k in ref:
+        denom = ref[k].norm().item() + 1e-12
+        assert (grads[k] - ref[k]).norm().item() / denom < 2e-4, k
+    for k, v in sub(g, "bn1").items():
+        torch.testing.assert_close(sd[k], v, **TOL)
+
+
+def test_taps(golden):
+    name, g, cfg, B = golden
+    taps_ref = sub(g, "tap")
+    if not taps_ref:
+        pytest.skip("no taps recorded for this config")
+    sd = _clone(sub(g, "state0"))
+    taps = {}
+    R.p_loss(sd, cfg, g["x0"], g["eps"], g["t"], True, None, taps)
+    for k, v in taps_ref.items():
+        torch.testing.assert_close(taps[k], v, **TOL)
+
+
+def test_three_adamw_steps(golden):
+    name, g, cfg, B = golden
+    sd = _clone(sub(g, "state0"))
+    names = [k for k in sd if R.is_param(k)]
+    m = {k: torch.zeros_like(sd[k]) for k in names}
+    v = {k: torch.zeros_like(sd[k]) for k in names}
+    losses = []
+    for step in range(3):
+        torch.manual_seed(100 + step)
+        eps = torch.randn_like(g["x0"])
+        t = torch.rand((B, 1, 1, 1))
+        loss, grads = R.loss_and_grads(sd, cfg, g["x0"], eps, t, _masks(g, cfg, f"step{step}/"))
+        R.adamw_step({k: sd[k] for k in names}, grads, m, v, step + 1,
+                     cfg["learning_rate"], cfg["weight_decay"])
+        losses.append(loss)
+    torch.testing.assert_close(torch.stack(losses), g["loss_steps"], rtol=2e-4, atol=0)
+    for k, ref in sub(g, "state3").items():
+        if ref.dtype == torch.int64:
+            assert torch.equal(sd[k], ref), k
+        elif k in noise_keys(g):
+            # gradient is rounding noise (bias in front of a train-mode BatchNorm): Adam turns
+            # noise into +-lr steps, so only the step bound is checkable.
+            assert (sd[k] - ref).abs().max().item() <= 2 * 3 * cfg["learning_rate"] * 1.05, k
+        else:
+            assert (sd[k] - ref).norm().item() <= 2e-4 * (ref.norm().item() + 1e-6), k
+
+
+def test_eval_loss_and_sampler(golden):
+    name, g, cfg, B = golden
+    sd = _clone(sub(g, "state3"))
+    torch.manual_seed(200)
+    eps = torch.randn_like(g["x0"])
+    t = torch.rand((B, 1, 1, 1))
+    val = R.p_loss(sd, cfg, g["x0"], eps, t, training=False)
+    torch.testing.assert_close(val.reshape(1), g["val_loss"], rtol=1e-5, atol=0)
+    for T in (1, 4):
+        out = R.reverse_diffusion(sd, cfg, g["gen_noise"].clone(), T)
+        ref = g[f"gen_T{T}"]
+        assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
