@@ -1,0 +1,215 @@
+/*
+ * vision_amd.h -- C ABI of libvision_amd.so: hand-written gfx950 (MI355X) HIP kernels for the
+ * DDPM UNet training step and sampler of HansaemIanOh/vision `models/ddpm.py`.
+ *
+ * The reference is pure Python on torch; it has no FFI of its own.  Each entry point below
+ * therefore cites the reference *call site* (file:line) whose torch operator(s) it replaces.
+ * A maintainer binds these with ctypes; `vision_amd/_lib.py` is that binding.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller.  The library never allocates,
+ *     frees or synchronises; every call is asynchronous on `stream` (a hipStream_t passed as
+ *     void*, NULL = the default stream).
+ *   - Activations are NHWC: [B][H][W][C], element type `dtype` (VAMD_F32 or VAMD_BF16).
+ *     Statistics, biases, gradients of parameters and optimiser state are always fp32.
+ *   - Convolution weights for the kernels are [Cout][kh][kw][Cin] in `dtype`
+ *     (vamd_repack_weight converts from torch's fp32 [Cout][Cin][kh][kw]).
+ *   - Return value: 0 ok; <0 invalid argument (text in vamd_last_error()); >0 a hipError_t.
+ */
+#ifndef VISION_AMD_H
+#define VISION_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VAMD_F32 = 0, VAMD_BF16 = 1 };
+enum { VAMD_OK = 0, VAMD_EINVAL = -1, VAMD_EUNSUPPORTED = -2 };
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char* vamd_last_error(void);
+/* Library / ABI version, and whether the MFMA path is compiled in. */
+int vamd_version(void);
+
+/* ------------------------------------------------------------------ convolution
+ * One descriptor for nn.Conv2d 3x3 pad 1 stride 1|2, 1x1 pad 0, and "nearest 2x upsample then
+ * 3x3 conv" (upsample = 1).  H, W are the stored input extents (before upsampling). */
+typedef struct vamd_conv_desc {
+    int32_t B, H, W, Cin, Cout;
+    int32_t ksize;     /* 1 or 3 */
+    int32_t stride;    /* 1 or 2 */
+    int32_t pad;       /* 0 or 1 */
+    int32_t upsample;  /* 1: input is read through a nearest-neighbour 2x upsample */
+    int32_t dtype;     /* VAMD_F32 | VAMD_BF16 (activations and packed weights) */
+    int32_t algo;      /* 0 auto, 1 force direct kernels, 2 force MFMA kernels */
+} vamd_conv_desc;
+
+/* y = conv(x, w) + bias[c] + temb[b][c] + residual + residual2; each addend may be NULL.
+ * residual2 carries the UNet skip tensor that the reference adds in place to the input of the
+ * next up-path module (`h += skip[index]`, models/ddpm.py:231), folded into the producer.
+ * Replaces nn.Conv2d at models/ddpm.py:19,35,52,59,68,95-98,156-157,203, the broadcast add of
+ * the projected time embedding `h += temb` (:78), the residual `x + h` (:87, :123) and
+ * nn.Upsample (:33) when desc.upsample. */
+int vamd_conv2d_fwd(const vamd_conv_desc* d, const void* x, const void* w, const float* bias,
+                    const float* temb, const void* residual, const void* residual2, void* y,
+                    void* stream);
+
+/* dx = conv_transpose(dy, w) (+ add).  `w_t` is the weight packed for the input gradient,
+ * [Cin][kh][kw][Cout] with both kernel axes flipped (vamd_repack_weight makes it).
+ * `add` (same shape as dx, may be NULL) is summed in: the second gradient stream of a residual.
+ * Autograd mirror of the call sites listed for vamd_conv2d_fwd. */
+int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, const void* add,
+                      void* dx, void* workspace, size_t workspace_bytes, void* stream);
+/* Scratch bytes vamd_conv2d_dgrad needs for this descriptor (0 for most; the gradient through the
+ * fused upsample is formed at the upsampled resolution first). */
+size_t vamd_conv2d_dgrad_workspace(const vamd_conv_desc* d);
+
+/* dw[Cout][kh][kw][Cin] (fp32) = sum over pixels of dy (x) x.  Overwrites dw. */
+int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw,
+                      void* stream);
+
+/* fp32 [Cout][Cin][k][k] (torch layout) -> w_fwd [Cout][k][k][Cin] and, if non-NULL,
+ * w_dgrad [Cin][k][k][Cout] flipped, both in `dtype`. */
+int vamd_repack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin,
+                       int ksize, int dtype, void* stream);
+/* fp32 [Cout][k][k][Cin] -> fp32 [Cout][Cin][k][k] (gradient back to torch layout). */
+int vamd_unpack_wgrad(const float* dw_krsc, float* dw_oihw, int Cout, int Cin, int ksize,
+                      void* stream);
+
+/* ------------------------------------------------------- normalisation + activation
+ * Per-(g, c) sum and sum of squares of x viewed as [G][R][C] (BatchNorm: G = 1, R = B*H*W;
+ * GroupNorm / per-image sums: G = B, R = H*W).  `partial` holds G * nchunk * C * 2 floats,
+ * nchunk = vamd_stats_chunks(R).  Deterministic (no atomics).
+ * Replaces the statistics half of nn.BatchNorm2d (models/ddpm.py:50,56) / nn.GroupNorm (:93). */
+int vamd_stats_chunks(int64_t R);
+int vamd_chan_stats(const void* x, float* partial, int G, int64_t R, int C, int dtype,
+                    void* stream);
+/* As vamd_chan_stats, for the backward pass: sums of gz and gz*xhat where
+ * z = x*scale+shift, gz = dy * mask * (z > 0 ? 1 : slope), xhat = (x - mean) * rstd.
+ * scale/shift/mean/rstd are [G][C] fp32; mask may be NULL; slope = 1 disables the activation. */
+int vamd_norm_bwd_stats(const void* dy, const void* x, const void* mask, const float* scale,
+                        const float* shift, const float* mean, const float* rstd, float slope,
+                        float* partial, int G, int64_t R, int C, int dtype, void* stream);
+
+/* BatchNorm finalise (training = 1: batch statistics from `partial`, running statistics updated
+ * with `momentum`, unbiased variance, num_batches_tracked += 1; training = 0: running statistics).
+ * Outputs (each [C]): scale = gamma*rstd, shift = beta - mean*scale, mean, rstd. */
+int vamd_bn_finalize(const float* partial, int nchunk, int C, int64_t count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float momentum, float eps, int training,
+                     float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* GroupNorm finalise: groups of C/groups channels per image; outputs are [B][C]. */
+int vamd_gn_finalize(const float* partial, int nchunk, int B, int C, int groups, int64_t HW,
+                     const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                     float* mean, float* rstd, void* stream);
+/* y = leaky_relu(x*scale[g][c] + shift[g][c], slope) * mask.  slope = 1: no activation;
+ * mask (pre-scaled dropout mask, same shape as x) may be NULL.
+ * Replaces BatchNorm2d/GroupNorm apply + nn.LeakyReLU (models/ddpm.py:51,57,144) + nn.Dropout (:58). */
+int vamd_scale_shift_act(const void* x, const float* scale, const float* shift, const void* mask,
+                         float slope, void* y, int G, int64_t R, int C, int dtype, void* stream);
+/* Backward finalise for BatchNorm: dgamma, dbeta and the three per-channel coefficients of
+ * dx = cA*gz + cB + cC*xhat. */
+int vamd_bn_bwd_finalize(const float* partial, int nchunk, int C, int64_t count,
+                         const float* scale, float* dgamma, float* dbeta, float* cA, float* cB,
+                         float* cC, void* stream);
+/* Backward finalise for GroupNorm (coefficients are [B][C]). */
+int vamd_gn_bwd_finalize(const float* partial, int nchunk, int B, int C, int groups, int64_t HW,
+                         const float* gamma, const float* rstd, float* dgamma, float* dbeta,
+                         float* cA, float* cB, float* cC, void* stream);
+/* dx = cA*gz + cB + cC*xhat (+ add + add2), gz and xhat as in vamd_norm_bwd_stats.  add / add2
+ * merge the other gradient streams reaching x (residual shortcut, UNet skip). */
+int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const float* scale,
+                        const float* shift, const float* mean, const float* rstd, float slope,
+                        const float* cA, const float* cB, const float* cC, const void* add,
+                        const void* add2, void* dx, int G, int64_t R, int C, int dtype,
+                        void* stream);
+/* Sums partial [G][nchunk][C][2] to per_g[G][C] (component 0) and total[C] = sum over g.
+ * Used for the gradients of conv bias and of the projected time embedding. */
+int vamd_sum_finalize(const float* partial, int nchunk, int G, int C, float* per_g, float* total,
+                      void* stream);
+
+/* ------------------------------------------------------------------- attention core
+ * Batched products with padded rows: lda/ldb/ldc are element strides between rows, batch z of an
+ * operand with R rows starts at z*R*ld.  Padding columns that the MFMA path reads (up to the next
+ * 16 bytes of a row) must hold zeros.
+ * NT: C[z][m][n] = alpha * sum_k A[z][m][k] * Bm[z][n][k]; C is fp32 if out_f32 else `dtype`.
+ * TN: C[z][m][n] = alpha * sum_k A[z][k][m] * Bm[z][k][n].
+ * Replace the two einsums at models/ddpm.py:117,120 and their gradients. */
+int vamd_bmm_nt(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, int lda,
+                int ldb, int ldc, float alpha, int dtype, int out_f32, int algo, void* stream);
+int vamd_bmm_tn(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, int lda,
+                int ldb, int ldc, float alpha, int dtype, int algo, void* stream);
+/* y[b][h][w][c] = sum of the 2x2 block of x [B][2H][2W][C]: gradient of nn.Upsample (models/ddpm.py:33). */
+int vamd_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+/* x [batch][R][C] -> y [batch][C][ldy] (ldy >= R; padding columns are left untouched). */
+int vamd_transpose(const void* x, void* y, int batch, int R, int C, int ldy, int dtype, void* stream);
+/* Row softmax over the first `cols` entries of rows of stride ld (F.softmax, models/ddpm.py:118)
+ * and its gradient ds = alpha * p * (dp - sum(dp * p)).  x and dp are fp32, p and ds are `dtype`. */
+int vamd_softmax_rows(const float* x, void* y, int64_t rows, int cols, int ld, int dtype,
+                      void* stream);
+int vamd_softmax_rows_bwd(const void* p, const float* dp, void* ds, int64_t rows, int cols, int ld,
+                          float alpha, int dtype, void* stream);
+/* y = a + b elementwise (the in-place skip add `h += skip[index]`, models/ddpm.py:231). */
+int vamd_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
+
+/* ----------------------------------------------------------- time-embedding path (fp32)
+ * emb[b] = [sin(w_j*t_b), cos(w_j*t_b)], w_j = 2*pi*exp(linspace(0, ln 1000, dim/2)) passed in
+ * `angular_speeds` (dim/2 floats, tabulated once by the host exactly as models/ddpm.py:126-134). */
+int vamd_timeembed(const float* t, const float* angular_speeds, float* emb, int B, int dim,
+                   void* stream);
+/* y[b][o] = sum_i act(x[b][i]) * W[o][i] + bias[o]; act = LeakyReLU(slope) if act_in else id.
+ * The 1x1 convs on [B,C,1,1] maps at models/ddpm.py:156-157,215-217 and ResNetBlock.linear_temb (:47,77). */
+int vamd_linear_fwd(const float* x, const float* W, const float* bias, float* y, int B, int I,
+                    int O, int act_in, float slope, void* stream);
+/* dx (may be NULL), dW, dbias of vamd_linear_fwd.  accumulate_dx: dx += instead of =. */
+int vamd_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW,
+                    float* dbias, int B, int I, int O, int act_in, float slope,
+                    int accumulate_dx, void* stream);
+
+/* ------------------------------------------------------------ diffusion elementwise
+ * Cosine schedule + forward noising, fused with the NCHW fp32 -> NHWC `dtype` conversion:
+ * angle = acos(.95) + t*(acos(.02)-acos(.95)); n = sin, s = cos; x_t = s*x0 + n*eps.
+ * Writes n[B], s[B], n2[B] = n*n.  models/ddpm.py:242-255, :264-266, :258. */
+int vamd_qsample(const float* x0_nchw, const float* eps_nchw, const float* t, void* xt_nhwc,
+                 float* n, float* s, float* n2, int B, int C, int H, int W, int dtype,
+                 void* stream);
+/* schedule only (sampler): n, s, n2 for t[B]. */
+int vamd_schedule(const float* t, float* n, float* s, float* n2, int B, void* stream);
+/* loss = mean |pred - eps| (F.l1_loss, models/ddpm.py:268): pred NHWC `dtype`, eps NCHW fp32.
+ * `partial` needs vamd_l1_chunks(n) floats; loss is one float. */
+int vamd_l1_chunks(int64_t n);
+int vamd_l1_loss_fwd(const void* pred_nhwc, const float* eps_nchw, float* partial, float* loss,
+                     int B, int C, int H, int W, int dtype, void* stream);
+/* dpred = gout[0] * sign(pred - eps) / numel. */
+int vamd_l1_loss_bwd(const void* pred_nhwc, const float* eps_nchw, const float* gout,
+                     void* dpred_nhwc, int B, int C, int H, int W, int dtype, void* stream);
+/* One step of the deterministic sampler, models/ddpm.py:259 and :285-287:
+ * x0_hat = (cur - n*eps_hat)/s ; cur <- s_next*x0_hat + n_next*eps_hat.
+ * cur is fp32 NHWC (updated in place), next_in is the `dtype` copy fed to the network,
+ * pred_images_nchw (may be NULL) receives x0_hat in NCHW fp32. */
+int vamd_denoise_step(float* cur_nhwc, const void* eps_hat_nhwc, const float* n, const float* s,
+                      const float* n_next, const float* s_next, void* next_in_nhwc,
+                      float* pred_images_nchw, int B, int C, int H, int W, int dtype,
+                      void* stream);
+/* Layout / dtype converters at the module boundary (forward(x, t) takes and returns NCHW fp32).
+ * f32_copy_nhwc (may be NULL) additionally receives an fp32 NHWC copy. */
+int vamd_nchw_to_nhwc(const float* x_nchw, void* y_nhwc, float* f32_copy_nhwc, int B, int C,
+                      int H, int W, int dtype, void* stream);
+int vamd_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int B, int C, int H, int W, int dtype,
+                      void* stream);
+
+/* ------------------------------------------------------------------------ optimiser
+ * torch.optim.AdamW (models/ddpm.py:340-345) over one flat fp32 arena of n elements.
+ * lr is read from the device (lr_dev[0]) when lr_dev != NULL, else `lr`.  step is 1-based.
+ * grad_scale multiplies the gradient first (1/world_size for a summed all-reduce). */
+int vamd_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+               const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+               int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISION_AMD_H */

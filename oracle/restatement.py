@@ -124,11 +124,17 @@ def is_param(name: str) -> bool:
 
 # ---------------------------------------------------------------------- primitives
 def timeembed(t: torch.Tensor, dim: int) -> torch.Tensor:
-    """Sinusoidal embedding of t [B,1,1,1] -> [B,dim,1,1]; reference models/ddpm.py:125-136."""
+    """Sinusoidal embedding of t [B,1,1,1] -> [B,dim,1,1]; reference models/ddpm.py:125-136.
+
+    The angles reach 2*pi*1000*t ~ 6e3 rad, where one float32 ulp is 5e-4 rad: the float32
+    rounding of the angle is part of what the reference computes.  The angles are therefore always
+    formed in float32, also when the rest of the network is evaluated in float64."""
+    out_dtype = t.dtype
+    t = t.float()
     f = torch.exp(torch.linspace(math.log(1.0), math.log(1000.0), dim // 2,
                                  device=t.device)).reshape(1, dim // 2, 1, 1)
     w = 2.0 * math.pi * f
-    return torch.cat([torch.sin(w * t), torch.cos(w * t)], dim=1)
+    return torch.cat([torch.sin(w * t), torch.cos(w * t)], dim=1).to(out_dtype)
 
 
 def diffusion_schedule(t: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -242,9 +248,11 @@ def unet_forward(sd, cfg, x, t, training=False, drop_masks=None, taps=None):
 def p_loss(sd, cfg, images, noises, diffusion_times, training=True, drop_masks=None, taps=None):
     """L1 noise-prediction loss; reference models/ddpm.py:262-269 with the two random
     draws (`randn_like` :263, `rand` :264) supplied by the caller."""
-    n, s = diffusion_schedule(diffusion_times)
+    n, s = diffusion_schedule(diffusion_times.float())       # rates are float32 in the reference
+    t_net = (n ** 2).to(images.dtype)                        # network conditioning, :258
+    n, s = n.to(images.dtype), s.to(images.dtype)
     noisy = s * images + n * noises
-    pred = unet_forward(sd, cfg, noisy, n ** 2, training, drop_masks, taps)   # denoise, :257-258
+    pred = unet_forward(sd, cfg, noisy, t_net, training, drop_masks, taps)    # denoise, :257-258
     if taps is not None:
         taps["pred_noises"] = pred
     return F.l1_loss(pred, noises)

@@ -35,10 +35,11 @@ def sub(tensors, prefix):
 
 def noise_keys(tensors):
     """Parameters whose exact gradient is zero: conv / temb-projection biases that feed a
-    train-mode BatchNorm (the mean subtraction cancels them).  Their computed gradient is
+    train-mode BatchNorm (the mean subtraction cancels them) and the key-projection bias of the
+    attention block (it shifts every score of a softmax row equally).  Their computed gradient is
     rounding noise, ~1e-9 in the golden vectors."""
     return {k[len("grad/"):] for k in tensors
-            if k.startswith("grad/") and k.endswith((".block1.0.2.bias", ".linear_temb.bias"))}
+            if k.startswith("grad/") and k.endswith((".block1.0.2.bias", ".linear_temb.bias", ".k_proj.bias"))}
 
 
 @pytest.fixture(scope="session", params=["t0", "t1", "t0_drop"])

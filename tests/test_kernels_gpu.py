@@ -1,0 +1,429 @@
+"""Per-kernel parity of libvision_amd.so (through the C ABI) against fp64 torch-CPU evaluations of the
+same operator on the same (dtype-rounded) inputs.  Run on the MI355X box: pytest -m gpu."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from vision_amd import _lib                      # noqa: E402
+from vision_amd._lib import ConvDesc, call, lib   # noqa: E402
+
+DEV = torch.device("cuda:0")
+DT = {"f32": (torch.float32, _lib.F32), "bf16": (torch.bfloat16, _lib.BF16)}
+# relative Frobenius-norm error allowed for outputs stored in the compute dtype / in fp32
+TOL_OUT = {"f32": 2e-5, "bf16": 4e-3}
+TOL_F32OUT = {"f32": 2e-5, "bf16": 2e-4}
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_KEEP = []
+
+
+def P(t):
+    """Device pointer of t; t is kept alive until the end of the test (a temporary passed by
+    pointer would otherwise be freed, and its block reused by the next temporary, before the
+    asynchronous kernel reads it)."""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    return t.data_ptr()
+
+
+@pytest.fixture(autouse=True)
+def _release_temporaries():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def rnd(shape, tdt, gen, scale=1.0):
+    """Random tensor rounded to the compute dtype; returns (device tensor in tdt, fp64 CPU copy)."""
+    x = (torch.randn(shape, generator=gen) * scale).to(tdt)
+    return x.to(DEV), x.double()
+
+
+def nhwc(x_nchw64):
+    return x_nchw64.permute(0, 2, 3, 1).contiguous()
+
+
+def pack_weights(w64, tdt, dt):
+    """fp32 OIHW -> packed forward / dgrad copies through vamd_repack_weight."""
+    O, I, k, _ = w64.shape
+    w32 = w64.float().to(DEV).contiguous()
+    wf = torch.empty((O, k, k, I), dtype=tdt, device=DEV)
+    wd = torch.empty((I, k, k, O), dtype=tdt, device=DEV)
+    call("vamd_repack_weight", P(w32), P(wf), P(wd), O, I, k, dt, S())
+    return wf, wd
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, up
+    (2, 12, 12, 64, 64, 3, 1, 0),
+    (3, 9, 7, 32, 64, 3, 1, 0),
+    (2, 10, 10, 64, 32, 3, 1, 0),
+    (1, 13, 11, 128, 192, 3, 1, 0),
+    (2, 12, 12, 64, 64, 3, 2, 0),
+    (2, 7, 9, 32, 32, 3, 2, 0),
+    (2, 6, 5, 64, 64, 3, 1, 1),
+    (2, 9, 9, 64, 128, 1, 1, 0),
+    (2, 16, 16, 3, 32, 3, 1, 0),
+    (2, 16, 16, 32, 3, 3, 1, 0),
+    (2, 8, 8, 3, 3, 3, 1, 0),
+    (2, 8, 8, 3, 32, 1, 1, 0),
+    (2, 8, 8, 3, 3, 1, 1, 0),
+]
+
+
+def conv_ref(x64, w64, stride, up, k):
+    if up:
+        x64 = F.interpolate(x64, scale_factor=2, mode="nearest")
+    return F.conv2d(x64, w64, None, stride=stride, padding=1 if k == 3 else 0)
+
+
+def mfma_ok(cin, cout, dts):
+    piece, kstep = (8, 64) if dts == "bf16" else (4, 32)
+    return cin % piece == 0 and 2 * cin >= kstep and cout % piece == 0
+
+
+@pytest.mark.parametrize("algo", [_lib.ALGO_DIRECT, _lib.ALGO_MFMA])
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dts, algo):
+    B, H, W, Cin, Cout, k, stride, up = case
+    if algo == _lib.ALGO_MFMA and not (mfma_ok(Cin, Cout, dts) and mfma_ok(Cout, Cin, dts)):
+        pytest.skip("shape outside the MFMA path")
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(hash(case) % 1000)
+    x, x64 = rnd((B, Cin, H, W), tdt, gen)
+    w_, w64 = rnd((Cout, Cin, k, k), tdt, gen, 1.0 / math.sqrt(Cin * k * k))
+    wf, wd = pack_weights(w64, tdt, dt)
+    x64.requires_grad_(True)
+    w64.requires_grad_(True)
+    y64 = conv_ref(x64, w64, stride, up, k)
+    Ho, Wo = y64.shape[2], y64.shape[3]
+    bias = torch.randn(Cout, generator=gen)
+    temb = torch.randn(B, Cout, generator=gen)
+    res, res64 = rnd((B, Cout, Ho, Wo), tdt, gen)
+    res2, res264 = rnd((B, Cout, Ho, Wo), tdt, gen)
+    full64 = y64 + bias.double()[None, :, None, None] + temb.double()[:, :, None, None] + res64 + res264
+
+    d = ConvDesc(B, H, W, Cin, Cout, k, stride, 1 if k == 3 else 0, up, dt, algo)
+    xn = nhwc(x).contiguous()
+    y = torch.empty((B, Ho, Wo, Cout), dtype=tdt, device=DEV)
+    # plain conv
+    call("vamd_conv2d_fwd", C.byref(d), P(xn), P(wf), None, None, None, None, P(y), S())
+    assert relerr(y.permute(0, 3, 1, 2), y64.detach()) < TOL_OUT[dts]
+    # fused epilogue
+    call("vamd_conv2d_fwd", C.byref(d), P(xn), P(wf), P(bias.to(DEV)), P(temb.to(DEV)), P(nhwc(res)), P(nhwc(res2)), P(y), S())
+    assert relerr(y.permute(0, 3, 1, 2), full64.detach()) < TOL_OUT[dts]
+
+    dy, dy64 = rnd((B, Cout, Ho, Wo), tdt, gen)
+    gx64, gw64 = torch.autograd.grad(y64, [x64, w64], dy64)
+    add, add64 = rnd((B, Cin, H, W), tdt, gen)
+    dyn = nhwc(dy)
+    dx = torch.empty((B, H, W, Cin), dtype=tdt, device=DEV)
+    nbytes = lib.vamd_conv2d_dgrad_workspace(C.byref(d))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=DEV)
+    call("vamd_conv2d_dgrad", C.byref(d), P(dyn), P(wd), None, P(dx), P(ws), nbytes, S())
+    assert relerr(dx.permute(0, 3, 1, 2), gx64) < TOL_OUT[dts]
+    call("vamd_conv2d_dgrad", C.byref(d), P(dyn), P(wd), P(nhwc(add)), P(dx), P(ws), nbytes, S())
+    assert relerr(dx.permute(0, 3, 1, 2), gx64 + add64) < TOL_OUT[dts]
+
+    dwk = torch.full((Cout, k, k, Cin), 7.0, dtype=torch.float32, device=DEV)   # must be overwritten
+    call("vamd_conv2d_wgrad", C.byref(d), P(dyn), P(xn), P(dwk), S())
+    dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=DEV)
+    call("vamd_unpack_wgrad", P(dwk), P(dw), Cout, Cin, k, S())
+    assert relerr(dw, gw64) < TOL_F32OUT[dts]
+    assert relerr(dwk.permute(0, 3, 1, 2), gw64) < TOL_F32OUT[dts]
+
+
+def test_conv_rejects_bad_arguments():
+    d = ConvDesc(1, 4, 4, 8, 8, 5, 1, 2, 0, _lib.F32, 0)
+    x = torch.zeros(16, device=DEV)
+    rc = lib.vamd_conv2d_fwd(C.byref(d), P(x), P(x), None, None, None, None, P(x), S())
+    assert rc < 0 and b"3x3" in lib.vamd_last_error()
+    d = ConvDesc(1, 4, 4, 3, 3, 3, 1, 1, 0, _lib.BF16, _lib.ALGO_MFMA)
+    rc = lib.vamd_conv2d_fwd(C.byref(d), P(x), P(x), None, None, None, None, P(x), S())
+    assert rc < 0 and b"MFMA" in lib.vamd_last_error()
+    rc = lib.vamd_conv2d_fwd(C.byref(d), None, P(x), None, None, None, None, P(x), S())
+    assert rc < 0
+
+
+def padded(t64, ld, tdt):
+    """Zero-pad the last axis of a CPU tensor to ld and upload in the compute dtype."""
+    out = torch.zeros(t64.shape[:-1] + (ld,), dtype=tdt)
+    out[..., :t64.shape[-1]] = t64.to(tdt)
+    return out.to(DEV)
+
+
+@pytest.mark.parametrize("algo", [_lib.ALGO_DIRECT, _lib.ALGO_MFMA])
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 64, 64, 32), (2, 196, 196, 64), (2, 100, 40, 128), (5, 16, 200, 32),
+                                   (2, 196, 64, 196), (3, 50, 72, 30)])
+def test_bmm_nt_tn(shape, dts, algo):
+    """Batched NT / TN products with rows padded to 16-byte multiples (the 14x14 attention level has
+    196 positions: 196 is not a multiple of 8)."""
+    batch, M, N, K = shape
+    tdt, dt = DT[dts]
+    up8 = lambda v: (v + 7) // 8 * 8
+    gen = torch.Generator().manual_seed(M + N)
+    _, A64 = rnd((batch, M, K), tdt, gen)
+    _, B64 = rnd((batch, N, K), tdt, gen)
+    lda = ldb = up8(K)
+    ldc = up8(N)
+    A, Bm = padded(A64, lda, tdt), padded(B64, ldb, tdt)
+    ref = 0.37 * torch.bmm(A64, B64.transpose(1, 2))
+    out = torch.zeros((batch, M, ldc), dtype=tdt, device=DEV)
+    call("vamd_bmm_nt", P(A), P(Bm), P(out), batch, M, N, K, lda, ldb, ldc, 0.37, dt, 0, algo, S())
+    assert relerr(out[..., :N], ref) < TOL_OUT[dts]
+    assert float(out[..., N:].abs().max()) == 0.0 if ldc > N else True
+    out32 = torch.zeros((batch, M, ldc), dtype=torch.float32, device=DEV)
+    call("vamd_bmm_nt", P(A), P(Bm), P(out32), batch, M, N, K, lda, ldb, ldc, 0.37, dt, 1, algo, S())
+    assert relerr(out32[..., :N], ref) < TOL_F32OUT[dts]
+    # TN: C[m][n] = sum_k At[k][m] Bt[k][n]
+    _, At64 = rnd((batch, K, M), tdt, gen)
+    _, Bt64 = rnd((batch, K, N), tdt, gen)
+    At, Bt = padded(At64, up8(M), tdt), padded(Bt64, up8(N), tdt)
+    ref = torch.bmm(At64.transpose(1, 2), Bt64)
+    outt = torch.zeros((batch, M, ldc), dtype=tdt, device=DEV)
+    call("vamd_bmm_tn", P(At), P(Bt), P(outt), batch, M, N, K, up8(M), up8(N), ldc, 1.0, dt, algo, S())
+    assert relerr(outt[..., :N], ref) < TOL_OUT[dts]
+
+
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(4, 9, 9, 64), (3, 16, 16, 3), (2, 7, 5, 96), (2, 4, 4, 512)])
+def test_batchnorm_act_fwd_bwd(shape, dts):
+    B, H, W, Cc = shape
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(Cc)
+    x, x64 = rnd((B, Cc, H, W), tdt, gen, 2.0)
+    x = nhwc(x + 0)
+    x64 = x64.requires_grad_(True)
+    gamma = (torch.rand(Cc, generator=gen) + 0.5)
+    beta = torch.randn(Cc, generator=gen)
+    rm, rv = torch.randn(Cc, generator=gen), torch.rand(Cc, generator=gen) + 0.5
+    mask, mask64 = rnd((B, Cc, H, W), tdt, gen)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    y64 = F.leaky_relu(F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5), 0.01) * mask64
+
+    R = B * H * W
+    nchunk = lib.vamd_stats_chunks(R)
+    part = torch.empty((1, nchunk, Cc, 2), dtype=torch.float32, device=DEV)
+    call("vamd_chan_stats", P(x), P(part), 1, R, Cc, dt, S())
+    coef = torch.empty((4, Cc), dtype=torch.float32, device=DEV)
+    gm, bt, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    call("vamd_bn_finalize", P(part), nchunk, Cc, R, P(gm), P(bt), P(rmd), P(rvd), P(nbt), 0.1, 1e-5, 1,
+         P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), S())
+    y = torch.empty_like(x)
+    maskn = nhwc(mask)
+    call("vamd_scale_shift_act", P(x), P(coef[0]), P(coef[1]), P(maskn), 0.01, P(y), 1, R, Cc, dt, S())
+    assert relerr(y.permute(0, 3, 1, 2), y64.detach()) < TOL_OUT[dts]
+    assert relerr(rmd, rm64) < 1e-5 and relerr(rvd, rv64) < 1e-5 and int(nbt) == 1
+
+    dy, dy64 = rnd((B, Cc, H, W), tdt, gen)
+    gx, gg, gb = torch.autograd.grad(y64, [x64, g64, b64], dy64)
+    add, add64 = rnd((B, Cc, H, W), tdt, gen)
+    dyn = nhwc(dy)
+    call("vamd_norm_bwd_stats", P(dyn), P(x), P(maskn), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01,
+         P(part), 1, R, Cc, dt, S())
+    out = torch.empty((5, Cc), dtype=torch.float32, device=DEV)
+    call("vamd_bn_bwd_finalize", P(part), nchunk, Cc, R, P(coef[0]), P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(out[4]), S())
+    dx = torch.empty_like(x)
+    call("vamd_norm_bwd_apply", P(dyn), P(x), P(maskn), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01,
+         P(out[2]), P(out[3]), P(out[4]), P(nhwc(add)), None, P(dx), 1, R, Cc, dt, S())
+    assert relerr(out[0], gg) < 2e-4 and relerr(out[1], gb) < 2e-4
+    assert relerr(dx.permute(0, 3, 1, 2), gx + add64) < TOL_OUT[dts]
+
+    # eval mode: running statistics
+    call("vamd_bn_finalize", None, 0, Cc, 0, P(gm), P(bt), P(rmd), P(rvd), None, 0.1, 1e-5, 0,
+         P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), S())
+    call("vamd_scale_shift_act", P(x), P(coef[0]), P(coef[1]), None, 0.01, P(y), 1, R, Cc, dt, S())
+    ye = F.leaky_relu(F.batch_norm(x64.detach(), rmd.double().cpu(), rvd.double().cpu(), gamma.double(), beta.double(),
+                                   False, 0.1, 1e-5), 0.01)
+    assert relerr(y.permute(0, 3, 1, 2), ye) < TOL_OUT[dts]
+
+
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 8, 8, 32), (2, 14, 14, 512), (2, 5, 7, 64)])
+def test_groupnorm_fwd_bwd(shape, dts):
+    B, H, W, Cc = shape
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(Cc + 1)
+    x, x64 = rnd((B, Cc, H, W), tdt, gen, 1.5)
+    x = nhwc(x)
+    x64.requires_grad_(True)
+    gamma, beta = torch.rand(Cc, generator=gen) + 0.5, torch.randn(Cc, generator=gen)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y64 = F.group_norm(x64, 32, g64, b64, 1e-6)
+    R = H * W
+    nchunk = lib.vamd_stats_chunks(R)
+    part = torch.empty((B, nchunk, Cc, 2), dtype=torch.float32, device=DEV)
+    call("vamd_chan_stats", P(x), P(part), B, R, Cc, dt, S())
+    coef = torch.empty((4, B, Cc), dtype=torch.float32, device=DEV)
+    gm, bt = gamma.to(DEV), beta.to(DEV)
+    call("vamd_gn_finalize", P(part), nchunk, B, Cc, 32, R, P(gm), P(bt), 1e-6, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), S())
+    y = torch.empty_like(x)
+    call("vamd_scale_shift_act", P(x), P(coef[0]), P(coef[1]), None, 1.0, P(y), B, R, Cc, dt, S())
+    assert relerr(y.permute(0, 3, 1, 2), y64.detach()) < TOL_OUT[dts]
+    dy, dy64 = rnd((B, Cc, H, W), tdt, gen)
+    gx, gg, gb = torch.autograd.grad(y64, [x64, g64, b64], dy64)
+    dyn = nhwc(dy)
+    call("vamd_norm_bwd_stats", P(dyn), P(x), None, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 1.0, P(part), B, R, Cc, dt, S())
+    dgb = torch.empty((2, Cc), dtype=torch.float32, device=DEV)
+    abc = torch.empty((3, B, Cc), dtype=torch.float32, device=DEV)
+    call("vamd_gn_bwd_finalize", P(part), nchunk, B, Cc, 32, R, P(gm), P(coef[3]), P(dgb[0]), P(dgb[1]), P(abc[0]), P(abc[1]), P(abc[2]), S())
+    dx = torch.empty_like(x)
+    call("vamd_norm_bwd_apply", P(dyn), P(x), None, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 1.0,
+         P(abc[0]), P(abc[1]), P(abc[2]), None, None, P(dx), B, R, Cc, dt, S())
+    assert relerr(dgb[0], gg) < 2e-4 and relerr(dgb[1], gb) < 2e-4
+    assert relerr(dx.permute(0, 3, 1, 2), gx) < TOL_OUT[dts]
+
+
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+def test_softmax_transpose_add_sumpool(dts):
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(5)
+    rows, cols = 37, 196
+    x = (torch.randn((rows, cols), generator=gen) * 3).to(DEV)
+    p = torch.empty((rows, cols), dtype=tdt, device=DEV)
+    call("vamd_softmax_rows", P(x), P(p), rows, cols, cols, dt, S())
+    ref = torch.softmax(x.double().cpu(), -1)
+    assert relerr(p, ref) < TOL_OUT[dts]
+    dp = torch.randn((rows, cols), generator=gen).to(DEV)
+    ds = torch.empty_like(p)
+    call("vamd_softmax_rows_bwd", P(p), P(dp), P(ds), rows, cols, cols, 0.25, dt, S())
+    p64 = p.double().cpu()
+    refds = 0.25 * p64 * (dp.double().cpu() - (dp.double().cpu() * p64).sum(-1, keepdim=True))
+    assert relerr(ds, refds) < TOL_OUT[dts]
+
+    t, t64 = rnd((3, 45, 70), tdt, gen)
+    tt = torch.empty((3, 70, 45), dtype=tdt, device=DEV)
+    call("vamd_transpose", P(t), P(tt), 3, 45, 70, 45, dt, S())
+    assert torch.equal(tt.cpu().double(), t64.transpose(1, 2))
+
+    a, a64 = rnd((1003,), tdt, gen)
+    b, b64 = rnd((1003,), tdt, gen)
+    yv = torch.empty_like(a)
+    call("vamd_add", P(a), P(b), P(yv), 1003, dt, S())
+    assert relerr(yv, a64 + b64) < TOL_OUT[dts]
+
+    u, u64 = rnd((2, 6, 8, 16), tdt, gen)
+    sp = torch.empty((2, 3, 4, 16), dtype=tdt, device=DEV)
+    call("vamd_sumpool2x2", P(u), P(sp), 2, 3, 4, 16, dt, S())
+    refsp = u64.reshape(2, 3, 2, 4, 2, 16).sum((2, 4))
+    assert relerr(sp, refsp) < TOL_OUT[dts]
+
+
+def test_time_embedding_path():
+    gen = torch.Generator().manual_seed(9)
+    B, dim = 5, 32
+    t = torch.rand(B, generator=gen)
+    w = (2.0 * math.pi * torch.exp(torch.linspace(math.log(1.0), math.log(1000.0), dim // 2)))
+    emb = torch.empty((B, dim), device=DEV)
+    call("vamd_timeembed", P(t.to(DEV)), P(w.to(DEV)), P(emb), B, dim, S())
+    ang = w[None, :] * t[:, None]
+    ref = torch.cat([torch.sin(ang), torch.cos(ang)], 1)
+    assert (emb.cpu() - ref).abs().max().item() < 2e-6
+    I, O = 32, 48
+    x = torch.randn((B, I), generator=gen)
+    W_ = torch.randn((O, I), generator=gen) / 6
+    b_ = torch.randn(O, generator=gen)
+    for act in (0, 1):
+        x64, W64, b64 = x.double().requires_grad_(True), W_.double().requires_grad_(True), b_.double().requires_grad_(True)
+        y64 = F.linear(F.leaky_relu(x64, 0.01) if act else x64, W64, b64)
+        y = torch.empty((B, O), device=DEV)
+        call("vamd_linear_fwd", P(x.to(DEV)), P(W_.to(DEV)), P(b_.to(DEV)), P(y), B, I, O, act, 0.01, S())
+        assert relerr(y, y64.detach()) < 1e-5
+        dy = torch.randn((B, O), generator=gen)
+        gx, gw, gb = torch.autograd.grad(y64, [x64, W64, b64], dy.double())
+        dx = torch.ones((B, I), device=DEV)
+        dW, db = torch.empty((O, I), device=DEV), torch.empty(O, device=DEV)
+        call("vamd_linear_bwd", P(x.to(DEV)), P(W_.to(DEV)), P(dy.to(DEV)), P(dx), P(dW), P(db), B, I, O, act, 0.01, 1, S())
+        assert relerr(dx, gx + 1.0) < 1e-5 and relerr(dW, gw) < 1e-5 and relerr(db, gb) < 1e-5
+
+
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+def test_diffusion_elementwise(dts):
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(3)
+    B, Cc, H, W = 3, 3, 10, 6
+    x0, eps = torch.rand((B, Cc, H, W), generator=gen), torch.randn((B, Cc, H, W), generator=gen)
+    t = torch.rand(B, generator=gen)
+    lo, hi = torch.acos(torch.tensor(0.95)), torch.acos(torch.tensor(0.02))
+    ang = lo + t * (hi - lo)
+    n, s = torch.sin(ang), torch.cos(ang)
+    xt = torch.empty((B, H, W, Cc), dtype=tdt, device=DEV)
+    rates = torch.empty((3, B), device=DEV)
+    call("vamd_qsample", P(x0.to(DEV)), P(eps.to(DEV)), P(t.to(DEV)), P(xt), P(rates[0]), P(rates[1]), P(rates[2]),
+         B, Cc, H, W, dt, S())
+    ref = s[:, None, None, None] * x0 + n[:, None, None, None] * eps
+    assert relerr(xt.permute(0, 3, 1, 2), ref) < TOL_OUT[dts]
+    assert (rates[0].cpu() - n).abs().max() < 3e-7 and (rates[1].cpu() - s).abs().max() < 3e-7
+    assert (rates[2].cpu() - n * n).abs().max() < 3e-7
+    r2 = torch.empty((3, B), device=DEV)
+    call("vamd_schedule", P(t.to(DEV)), P(r2[0]), P(r2[1]), P(r2[2]), B, S())
+    assert torch.equal(r2, rates)
+
+    pred, pred64 = rnd((B, Cc, H, W), tdt, gen)
+    predn = nhwc(pred)
+    part = torch.empty(lib.vamd_l1_chunks(B * H * W), device=DEV)
+    loss = torch.empty((), device=DEV)
+    call("vamd_l1_loss_fwd", P(predn), P(eps.to(DEV)), P(part), P(loss), B, Cc, H, W, dt, S())
+    assert abs(loss.item() - (pred64 - eps.double()).abs().mean().item()) < 1e-6
+    g = torch.tensor([2.0], device=DEV)
+    dp = torch.empty_like(predn)
+    call("vamd_l1_loss_bwd", P(predn), P(eps.to(DEV)), P(g), P(dp), B, Cc, H, W, dt, S())
+    refg = 2.0 * torch.sign(pred64 - eps.double()) / pred64.numel()
+    assert relerr(dp.permute(0, 3, 1, 2), refg) < TOL_OUT[dts]
+
+    cur = torch.randn((B, Cc, H, W), generator=gen)
+    curd = torch.empty((B, H, W, Cc), device=DEV)
+    tmp = torch.empty((B, H, W, Cc), dtype=tdt, device=DEV)
+    call("vamd_nchw_to_nhwc", P(cur.to(DEV)), P(tmp), P(curd), B, Cc, H, W, dt, S())
+    assert torch.equal(curd.permute(0, 3, 1, 2).cpu(), cur)
+    back = torch.empty((B, Cc, H, W), device=DEV)
+    call("vamd_nhwc_to_nchw", P(tmp), P(back), B, Cc, H, W, dt, S())
+    assert relerr(back, cur) < TOL_OUT[dts]
+    n2, s2 = torch.rand(B, generator=gen), torch.rand(B, generator=gen) + 0.1
+    pi = torch.empty((B, Cc, H, W), device=DEV)
+    nxt = torch.empty((B, H, W, Cc), dtype=tdt, device=DEV)
+    call("vamd_denoise_step", P(curd), P(predn), P(n.to(DEV)), P(s.to(DEV)), P(n2.to(DEV)), P(s2.to(DEV)), P(nxt), P(pi),
+         B, Cc, H, W, dt, S())
+    bc = lambda v: v.double()[:, None, None, None]
+    x0h = (cur.double() - bc(n) * pred64) / bc(s)
+    assert relerr(pi, x0h) < 1e-5
+    assert relerr(curd.permute(0, 3, 1, 2), bc(s2) * x0h + bc(n2) * pred64) < 1e-5
+    assert relerr(nxt.permute(0, 3, 1, 2), bc(s2) * x0h + bc(n2) * pred64) < TOL_OUT[dts]
+
+
+def test_adamw_matches_torch():
+    gen = torch.Generator().manual_seed(1)
+    n = 1027
+    p0 = torch.randn(n, generator=gen)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-2, weight_decay=0.1)
+    p = p0.to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        g = torch.randn(n, generator=gen)
+        ref.grad = g.clone()
+        opt.step()
+        call("vamd_adamw", P(p), P((2 * g).to(DEV)), P(m), P(v), n, 1e-2, None, 0.9, 0.999, 1e-8, 0.1, step, 0.5, S())
+    assert relerr(p, ref.detach()) < 1e-6

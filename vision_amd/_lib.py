@@ -1,0 +1,90 @@
+"""ctypes binding of libvision_amd.so (the C ABI declared in include/vision_amd.h).
+
+The library is built in-tree by `python -m vision_amd.build_ext` (hipcc, gfx950).  There is no
+fallback: if the shared object is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvision_amd.so")
+
+F32, BF16 = 0, 1
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+
+
+class VamdError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "H", "W", "Cin", "Cout", "ksize", "stride", "pad", "upsample", "dtype", "algo")]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP extension first (python -m vision_amd.build_ext). "
+        "vision_amd has no CPU or eager fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+_p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_d = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/vision_amd.h one to one
+SIGNATURES = {
+    "vamd_last_error": (C.c_char_p, []),
+    "vamd_version": (_i, []),
+    "vamd_conv2d_fwd": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "vamd_conv2d_dgrad": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
+    "vamd_conv2d_dgrad_workspace": (_z, [_d]),
+    "vamd_conv2d_wgrad": (_i, [_d, _p, _p, _p, _p]),
+    "vamd_repack_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vamd_unpack_wgrad": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vamd_stats_chunks": (_i, [_l]),
+    "vamd_chan_stats": (_i, [_p, _p, _i, _l, _i, _i, _p]),
+    "vamd_norm_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _i, _p]),
+    "vamd_bn_finalize": (_i, [_p, _i, _i, _l, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
+    "vamd_gn_finalize": (_i, [_p, _i, _i, _i, _i, _l, _p, _p, _f, _p, _p, _p, _p, _p]),
+    "vamd_scale_shift_act": (_i, [_p, _p, _p, _p, _f, _p, _i, _l, _i, _i, _p]),
+    "vamd_bn_bwd_finalize": (_i, [_p, _i, _i, _l, _p, _p, _p, _p, _p, _p, _p]),
+    "vamd_gn_bwd_finalize": (_i, [_p, _i, _i, _i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "vamd_norm_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p]),
+    "vamd_sum_finalize": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "vamd_bmm_nt": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
+    "vamd_bmm_tn": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    "vamd_sumpool2x2": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_transpose": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_softmax_rows": (_i, [_p, _p, _l, _i, _i, _i, _p]),
+    "vamd_softmax_rows_bwd": (_i, [_p, _p, _p, _l, _i, _i, _f, _i, _p]),
+    "vamd_add": (_i, [_p, _p, _p, _l, _i, _p]),
+    "vamd_timeembed": (_i, [_p, _p, _p, _i, _i, _p]),
+    "vamd_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "vamd_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "vamd_qsample": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_schedule": (_i, [_p, _p, _p, _p, _i, _p]),
+    "vamd_l1_chunks": (_i, [_l]),
+    "vamd_l1_loss_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_l1_loss_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_denoise_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_nchw_to_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_adamw": (_i, [_p, _p, _p, _p, _l, _f, _p, _f, _f, _f, _f, _i, _f, _p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.vamd_last_error().decode(errors="replace")
+        raise VamdError(f"{what or 'libvision_amd'} failed (status {rc}): {msg}")
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise VamdError on a non-zero status."""
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,92 @@
+// C-ABI entry points of the convolution family: argument checks, then direct or MFMA kernels.
+#include "conv_shapes.h"
+
+namespace vamd {
+
+int conv_geom(const vamd_conv_desc* d, ConvGeom* g, const char* who) {
+    if (!d) return fail(VAMD_EINVAL, "%s: null descriptor", who);
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0)
+        return fail(VAMD_EINVAL, "%s: non-positive extent B=%d H=%d W=%d Cin=%d Cout=%d", who, d->B,
+                    d->H, d->W, d->Cin, d->Cout);
+    if (!((d->ksize == 3 && d->pad == 1) || (d->ksize == 1 && d->pad == 0)))
+        return fail(VAMD_EUNSUPPORTED, "%s: only 3x3 pad 1 and 1x1 pad 0 (got k=%d pad=%d)", who, d->ksize, d->pad);
+    if (d->stride != 1 && d->stride != 2)
+        return fail(VAMD_EUNSUPPORTED, "%s: stride must be 1 or 2 (got %d)", who, d->stride);
+    if (d->upsample && (d->stride != 1))
+        return fail(VAMD_EUNSUPPORTED, "%s: upsample needs stride 1", who);
+    if (d->dtype != VAMD_F32 && d->dtype != VAMD_BF16) return fail(VAMD_EINVAL, "%s: bad dtype %d", who, d->dtype);
+    g->B = d->B; g->H = d->H; g->W = d->W; g->Cin = d->Cin; g->Cout = d->Cout;
+    g->k = d->ksize; g->stride = d->stride; g->pad = d->pad; g->up = d->upsample ? 1 : 0;
+    g->He = g->up ? 2 * d->H : d->H;
+    g->We = g->up ? 2 * d->W : d->W;
+    g->Ho = (g->He + 2 * g->pad - g->k) / g->stride + 1;
+    g->Wo = (g->We + 2 * g->pad - g->k) / g->stride + 1;
+    g->M = (int64_t)g->B * g->Ho * g->Wo;
+    const int64_t esz = d->dtype == VAMD_BF16 ? 2 : 4;
+    const int64_t in_bytes = (int64_t)g->B * g->H * g->W * g->Cin * esz;
+    const int64_t out_bytes = g->M * g->Cout * esz;
+    if (in_bytes >= (1ll << 31) || out_bytes >= (1ll << 31))
+        return fail(VAMD_EUNSUPPORTED, "%s: tensor of %lld bytes exceeds the 2 GiB buffer-addressing limit",
+                    who, (long long)(in_bytes > out_bytes ? in_bytes : out_bytes));
+    return 0;
+}
+
+}  // namespace vamd
+
+using namespace vamd;
+
+extern "C" {
+
+int vamd_conv2d_fwd(const vamd_conv_desc* d, const void* x, const void* w, const float* bias,
+                    const float* temb, const void* residual, const void* residual2, void* y,
+                    void* stream) {
+    ConvGeom g;
+    int rc = conv_geom(d, &g, "vamd_conv2d_fwd");
+    if (rc) return rc;
+    VAMD_REQUIRE(x && w && y, "vamd_conv2d_fwd: null tensor");
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)y % 16 == 0,
+                 "vamd_conv2d_fwd: tensors must be 16-byte aligned");
+    const bool mfma = d->algo != 1 && conv_fwd_mfma_supported(g, d->dtype);
+    if (d->algo == 2 && !mfma)
+        return fail(VAMD_EUNSUPPORTED, "vamd_conv2d_fwd: MFMA path does not cover Cin=%d Cout=%d", g.Cin, g.Cout);
+    if (mfma) return conv_fwd_mfma(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
+    return conv_fwd_direct(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
+}
+
+size_t vamd_conv2d_dgrad_workspace(const vamd_conv_desc* d) {
+    ConvGeom g;
+    if (conv_geom(d, &g, "vamd_conv2d_dgrad_workspace")) return 0;
+    if (d->algo != 1 && conv_dgrad_mfma_supported(g, d->dtype)) return conv_dgrad_mfma_workspace(g, d->dtype);
+    return 0;
+}
+
+int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, const void* add,
+                      void* dx, void* workspace, size_t workspace_bytes, void* stream) {
+    ConvGeom g;
+    int rc = conv_geom(d, &g, "vamd_conv2d_dgrad");
+    if (rc) return rc;
+    VAMD_REQUIRE(dy && w_t && dx, "vamd_conv2d_dgrad: null tensor");
+    VAMD_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)w_t % 16 == 0 && (uintptr_t)dx % 16 == 0,
+                 "vamd_conv2d_dgrad: tensors must be 16-byte aligned");
+    const bool mfma = d->algo != 1 && conv_dgrad_mfma_supported(g, d->dtype);
+    if (d->algo == 2 && !mfma)
+        return fail(VAMD_EUNSUPPORTED, "vamd_conv2d_dgrad: MFMA path does not cover Cin=%d Cout=%d", g.Cin, g.Cout);
+    if (mfma) return conv_dgrad_mfma(g, d->dtype, dy, w_t, add, dx, workspace, workspace_bytes, as_stream(stream));
+    return conv_dgrad_direct(g, d->dtype, dy, w_t, add, dx, as_stream(stream));
+}
+
+int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
+    ConvGeom g;
+    int rc = conv_geom(d, &g, "vamd_conv2d_wgrad");
+    if (rc) return rc;
+    VAMD_REQUIRE(dy && x && dw, "vamd_conv2d_wgrad: null tensor");
+    VAMD_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dw % 16 == 0,
+                 "vamd_conv2d_wgrad: tensors must be 16-byte aligned");
+    const bool mfma = d->algo != 1 && conv_wgrad_mfma_supported(g, d->dtype);
+    if (d->algo == 2 && !mfma)
+        return fail(VAMD_EUNSUPPORTED, "vamd_conv2d_wgrad: MFMA path does not cover Cin=%d Cout=%d", g.Cin, g.Cout);
+    if (mfma) return conv_wgrad_mfma(g, d->dtype, dy, x, dw, as_stream(stream));
+    return conv_wgrad_direct(g, d->dtype, dy, x, dw, as_stream(stream));
+}
+
+}  // extern "C"

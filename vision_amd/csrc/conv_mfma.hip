@@ -1,0 +1,694 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores (MFMA), NHWC activations.
+//
+//   forward / input-gradient ("NT"):  Y[m][n]  = sum_{tap,c} Xg[m][tap][c] * W[n][tap][c]
+//   weight-gradient          ("TN"):  dW[n][f] = sum_m dY[m][n] * Xg[m][f],  f = (tap, c)
+//
+// m runs over output pixels (b, ho, wo), n over output channels; Xg is the input gathered through
+// the filter tap (with zero padding, stride 2, nearest-2x upsampling or zero-insertion).  Nothing
+// is materialised: every workgroup streams 16-byte pieces of the gathered operand straight from
+// global memory into LDS with `global_load_lds_dwordx4` (per-lane source address, linear LDS
+// destination), out-of-image pieces are fetched from a zero page.  Tiles are 128 x BN x (128 bytes
+// of reduction); 4 waves of 64 lanes, each wave owns a 64 x BN/2 block of 16x16 MFMA tiles with
+// fp32 accumulators.  LDS rows are XOR-swizzled (on the source side, as the LDS image of a
+// direct-to-LDS load is lane-linear) so that fragment reads are bank-conflict free.
+//
+// Element types: bf16 (v_mfma_f32_16x16x32_bf16) and fp32 (v_mfma_f32_16x16x4_f32, exact fp32).
+#include "conv_shapes.h"
+
+namespace vamd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct FastDiv {
+    uint32_t magic, shift;
+};
+static FastDiv make_fastdiv(uint32_t d) {       // exact for numerators < 2^26
+    uint32_t l = 0;
+    while ((1u << l) < d) ++l;
+    FastDiv f;
+    f.shift = 26 + l;
+    f.magic = (uint32_t)(((1ull << f.shift) + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t m, FastDiv d) {
+    return (uint32_t)(((uint64_t)m * d.magic) >> d.shift);
+}
+
+// How GEMM row m (an output pixel) and a filter tap address the stored input tensor.
+struct Gather {
+    int Hin, Win, Cin;     // stored input extents and channels
+    int ldx;               // elements between consecutive stored pixels (Cin unless rows are padded)
+    int He, We;            // valid range of the tap coordinate u = ho*stride + r - pad
+    int Ho, Wo;            // extents that m enumerates
+    int k, stride, pad;
+    int shift;             // 1: stored row = u >> 1 (nearest upsample or zero insertion)
+    int parity;            // 1: only even u, v carry data (zero insertion: dgrad of stride 2)
+    int M, Ktot;           // rows, and k*k*Cin
+    FastDiv div_howo, div_wo;
+};
+
+struct Epilogue {
+    const float* bias;     // [N]
+    const float* temb;     // [B][N]
+    const void* res;       // [M][N] in T
+    const void* res2;
+    float alpha;
+    int out_f32;           // store fp32 instead of T
+};
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<bf16_t> { static constexpr int PIECE = 8; };   // elements per 16 bytes
+template <> struct ElemTraits<float> { static constexpr int PIECE = 4; };
+
+constexpr int kBM = 128;
+constexpr int kRowBytes = 128;                   // reduction bytes per K-step
+
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous id range
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <typename T, int BN>
+__global__ void __launch_bounds__(256, 2)
+conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
+                    Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, int64_t strideA,
+                    int64_t strideB, int64_t strideC) {
+    constexpr int PIECE = ElemTraits<T>::PIECE;          // elements per 16-byte piece
+    constexpr int KSTEP = kRowBytes / sizeof(T);          // reduction elements per K-step
+    constexpr int A_BYTES = kBM * kRowBytes;
+    constexpr int B_BYTES = BN * kRowBytes;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NT = BN / 32;                           // 16-wide n tiles per wave
+    constexpr int LDC = BN + 4;                           // fp32 epilogue tile stride
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = bid / n_tiles, nt = bid - mt * n_tiles;
+    const int m0 = mt * kBM, n0 = nt * BN;
+    x += (int64_t)blockIdx.z * strideA;
+    w += (int64_t)blockIdx.z * strideB;
+
+    // ---- staging state: this thread copies piece `slot` of rows srow + 32*i
+    const int srow = tid >> 3, slot = tid & 7;
+    const int chunk = slot ^ (srow & 7);                 // logical piece held by this LDS slot
+    int a_ho[4], a_wo[4];
+    int64_t a_pix[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t m = m0 + srow + 32 * i;
+        a_ok[i] = m < (uint32_t)gp.M;
+        const uint32_t b = fdiv(m, gp.div_howo);
+        const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
+        const uint32_t ho = fdiv(rem, gp.div_wo);
+        a_ho[i] = (int)ho * gp.stride - gp.pad;
+        a_wo[i] = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad;
+        a_pix[i] = (int64_t)b * gp.Hin * gp.Win;
+    }
+    int f = chunk * PIECE;                               // flattened (tap, c) index of my piece
+    int c = f, tr = 0, ts = 0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+        if (c >= gp.Cin) { c -= gp.Cin; if (++ts == gp.k) { ts = 0; ++tr; } }
+
+    auto stage = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE;
+        const bool f_ok = f < gp.Ktot;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = a_ho[i] + tr, v = a_wo[i] + ts;
+            bool ok = a_ok[i] && f_ok && (unsigned)u < (unsigned)gp.He && (unsigned)v < (unsigned)gp.We;
+            if (gp.parity) ok = ok && (((u | v) & 1) == 0);
+            const int hi = u >> gp.shift, wi = v >> gp.shift;
+            const T* src = ok ? x + ((a_pix[i] + (int64_t)hi * gp.Win + wi) * gp.ldx + c)
+                              : reinterpret_cast<const T*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sa + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int n = n0 + srow + 32 * i;
+            const bool ok = f_ok && n < N;
+            const T* src = ok ? w + ((int64_t)n * ldw + f) : reinterpret_cast<const T*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+        f += KSTEP;
+        c += KSTEP;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            if (c >= gp.Cin) { c -= gp.Cin; if (++ts == gp.k) { ts = 0; ++tr; } }
+    };
+
+    f32x4_t acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fgrp = lane >> 4, fsw = lane & 7;
+    auto compute = [&](int buf) {
+        const unsigned char* sa = smem + buf * STAGE + (wm * 64 + frow) * kRowBytes;
+        const unsigned char* sb = smem + buf * STAGE + A_BYTES + (wn * (BN / 2) + frow) * kRowBytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int po = (((ks * 4 + fgrp) ^ fsw) << 4);
+            if constexpr (sizeof(T) == 2) {
+                bf16x8_t a[4], b[NT];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 16 * kRowBytes + po);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 16 * kRowBytes + po);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                f32x4_t a[4], b[NT];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(sa + i * 16 * kRowBytes + po);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(sb + j * 16 * kRowBytes + po);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nk = (gp.Ktot + KSTEP - 1) / KSTEP;
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) stage((t + 1) & 1);
+        compute(t & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> fp32 LDS tile -> coalesced 16-byte rows with the fused adds
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tile[(wm * 64 + i * 16 + fgrp * 4 + r) * LDC + wn * (BN / 2) + j * 16 + frow] = acc[i][j][r];
+    __syncthreads();
+
+    constexpr int G = BN / PIECE;                         // 16-byte output groups per row
+    const int grp = tid % G;
+    const int n = n0 + grp * PIECE;
+    // a trailing partial group (N not a multiple of PIECE) is written whole: its extra columns are
+    // exact zeros (their weight rows were never loaded) and ldc leaves room for them
+    if (n < N && n + PIECE <= ldc) {
+        float bv[PIECE];
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) bv[e] = (ep.bias && n + e < N) ? ep.bias[n + e] : 0.f;
+        const T* res = reinterpret_cast<const T*>(ep.res);
+        const T* res2 = reinterpret_cast<const T*>(ep.res2);
+        for (int row = tid / G; row < kBM; row += 256 / G) {
+            const uint32_t m = m0 + row;
+            if (m >= (uint32_t)gp.M) break;
+            float v[PIECE];
+#pragma unroll
+            for (int e = 0; e < PIECE; e += 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(tile + row * LDC + grp * PIECE + e);
+                v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) v[e] = v[e] * ep.alpha + bv[e];
+            const int64_t off = (int64_t)blockIdx.z * strideC + (int64_t)m * ldc + n;
+            if (ep.temb) {
+                const uint32_t b = fdiv(m, gp.div_howo);
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) if (n + e < N) v[e] += ep.temb[(int64_t)b * N + n + e];
+            }
+            if (res) {
+                const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res + off);
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[e] += to_f(rv.v[e]);
+            }
+            if (res2) {
+                const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res2 + off);
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[e] += to_f(rv.v[e]);
+            }
+            if (ep.out_f32) {
+                float* yo = reinterpret_cast<float*>(yout) + off;
+#pragma unroll
+                for (int e = 0; e < PIECE; e += 4)
+                    *reinterpret_cast<float4*>(yo + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+            } else {
+                Vec16<T> ov;
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) ov.v[e] = from_f<T>(v[e]);
+                *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + off) = ov;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: dW[n][f] += sum over a slice of pixels m of dY[m][n] * Xg[m][f].
+// Both operands are "reduction-major" in memory (channel innermost), so their MFMA fragments are
+// read with the transposing LDS read ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (fp32).
+// LDS stage: dY tile [KP pixels][128 n] and Xg tile [KP pixels][128 f], rows of 128 elements.
+// Grid: (n tiles * f tiles, split-K slices); partial tiles are combined with fp32 atomics.
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x, int N, int lda, int ldc,
+                    float* __restrict__ dw, int n_tiles, int f_tiles, int steps_per_slice,
+                    int64_t strideA, int64_t strideB, int64_t strideC, int out_mode, void* yout,
+                    float alpha) {
+    constexpr int PIECE = ElemTraits<T>::PIECE;
+    constexpr int ROWB = 128 * sizeof(T);                 // bytes per LDS row (128 elements)
+    constexpr int PPR = ROWB / 16;                        // 16-byte pieces per row
+    constexpr int KP = 16384 / ROWB;                      // pixels per K-step: 64 (bf16) / 32 (fp32)
+    constexpr int TILE_BYTES = KP * ROWB;                 // 16 KiB per operand
+    constexpr int STAGE = 2 * TILE_BYTES;
+    constexpr int RPI = 256 / PPR;                        // rows covered by one 256-thread pass
+    constexpr int NPASS = KP / RPI;                       // passes per operand tile (4)
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = blockIdx.x;
+    const int nt = bid / f_tiles, ft = bid - nt * f_tiles;
+    const int n0 = nt * 128, f0 = ft * 128;
+    dy += (int64_t)blockIdx.z * strideA;
+    x += (int64_t)blockIdx.z * strideB;
+
+    // staging: this thread copies physical piece `slot` of rows srow + RPI*i
+    const int srow = tid / PPR, slot = tid % PPR;
+    // swizzle in units of 32 bytes (bf16: the transposing read fetches 4 rows x 32 B per 16 lanes)
+    auto sw_of = [](int row) -> int {
+        if constexpr (sizeof(T) == 2) return (((row & 3) | (((row >> 3) & 1) << 2)) << 1);
+        else return 0;
+    };
+    // (RPI is a multiple of 16, so sw_of(srow + RPI*i) == sw_of(srow))
+    const int piece = slot ^ sw_of(srow);
+    // operand A (dY): column n0 + piece*PIECE
+    const int an = n0 + piece * PIECE;
+    const bool an_ok = an + PIECE <= lda && an < N;
+    // operand B (Xg): flattened column f0 + piece*PIECE -> (tap, c), fixed for the whole kernel
+    const int bf = f0 + piece * PIECE;
+    const bool bf_ok = bf < gp.Ktot;
+    const int tap = bf / gp.Cin;
+    const int bc = bf - tap * gp.Cin;
+    const int tr = tap / gp.k, ts = tap - tr * gp.k;
+
+    const int step0 = blockIdx.y * steps_per_slice;
+    const int total_steps = (gp.M + KP - 1) / KP;
+    int step1 = step0 + steps_per_slice;
+    if (step1 > total_steps) step1 = total_steps;
+
+    auto stage = [&](int buf, int step) {
+        unsigned char* sa = smem + buf * STAGE;
+        unsigned char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const uint32_t m = (uint32_t)step * KP + srow + RPI * i;
+            const bool m_ok = m < (uint32_t)gp.M;
+            const T* srcA = (m_ok && an_ok) ? dy + ((int64_t)m * lda + an) : reinterpret_cast<const T*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds(GPTR(srcA), LPTR(sa + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            const uint32_t b = fdiv(m, gp.div_howo);
+            const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
+            const uint32_t ho = fdiv(rem, gp.div_wo);
+            const int u = (int)ho * gp.stride - gp.pad + tr;
+            const int v = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad + ts;
+            bool ok = m_ok && bf_ok && (unsigned)u < (unsigned)gp.He && (unsigned)v < (unsigned)gp.We;
+            if (gp.parity) ok = ok && (((u | v) & 1) == 0);
+            const int hi = u >> gp.shift, wi = v >> gp.shift;
+            const T* srcB = ok ? x + ((((int64_t)b * gp.Hin + hi) * gp.Win + wi) * gp.ldx + bc)
+                               : reinterpret_cast<const T*>(g_zero_page);
+            __builtin_amdgcn_global_load_lds(GPTR(srcB), LPTR(sb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const unsigned char* sa = smem + buf * STAGE;
+        const unsigned char* sb = sa + TILE_BYTES;
+        if constexpr (sizeof(T) == 2) {
+            // 16x16x32 per k-step of 32 pixels; lane l supplies row k0 + ((l&15)>>2), cols c0 + 4*(l&3)
+            const int q = (lane & 15) >> 2, p = lane & 3, g = lane >> 4;
+#pragma unroll
+            for (int ks = 0; ks < KP / 32; ++ks) {
+                bf16x8_t a[4], b[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = ks * 32 + g * 8 + h * 4 + q;
+                    const int sw = sw_of(row);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int col = wm * 64 + i * 16 + p * 4;            // element column
+                        const int pc = (col >> 3) ^ sw;                      // physical 16-byte piece
+                        const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t*)(sa + row * ROWB + pc * 16 + (col & 7) * 2));
+                        const int colb = wn * 64 + i * 16 + p * 4;
+                        const int pcb = (colb >> 3) ^ sw;
+                        const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t*)(sb + row * ROWB + pcb * 16 + (colb & 7) * 2));
+                        const bf16x4_t fa = __builtin_bit_cast(bf16x4_t, va);
+                        const bf16x4_t fb = __builtin_bit_cast(bf16x4_t, vb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[i][h * 4 + e] = fa[e]; b[i][h * 4 + e] = fb[e]; }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // 16x16x4 fp32: lane l holds A[i = l&15][k = l>>4]; tile rows are pixels, so element
+            // (k, i) sits at row k, column i: plain 4-byte reads, 16 consecutive lanes contiguous.
+            const int fr = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int ks = 0; ks < KP / 4; ++ks) {
+                const int row = ks * 4 + g;
+                float a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[i] = *reinterpret_cast<const float*>(sa + row * ROWB + (wm * 64 + i * 16 + fr) * 4);
+                    b[i] = *reinterpret_cast<const float*>(sb + row * ROWB + (wn * 64 + i * 16 + fr) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if (step0 < step1) {
+        stage(0, step0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = step0; t < step1; ++t) {
+            if (t + 1 < step1) stage((t + 1 - step0) & 1, t + 1);
+            compute((t - step0) & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // D layout: column (second operand index) = lane & 15, row (first operand index) = 4*(lane>>4)+r
+    const int fr = lane & 15, fq = lane >> 4;
+    if (out_mode == 0) {
+        // dW[n][f] fp32, atomically accumulated across split-K slices
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int fcol = f0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nrow = n0 + wm * 64 + i * 16 + fq * 4 + r;
+                    if (nrow < N && fcol < gp.Ktot)
+                        atomicAdd(dw + (int64_t)blockIdx.z * strideC + (int64_t)nrow * ldc + fcol, acc[i][j][r]);
+                }
+            }
+    } else {
+        // plain batched TN product (attention): C[z][n][f] = alpha * acc, stored in T, no split-K
+        T* out = reinterpret_cast<T*>(yout) + (int64_t)blockIdx.z * strideC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int fcol = f0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nrow = n0 + wm * 64 + i * 16 + fq * 4 + r;
+                    if (nrow < N && fcol < gp.Ktot)
+                        out[(int64_t)nrow * ldc + fcol] = from_f<T>(alpha * acc[i][j][r]);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------ host side
+static Gather make_gather(int Hin, int Win, int Cin, int He, int We, int Ho, int Wo, int k, int stride,
+                          int pad, int shift, int parity, int64_t M) {
+    Gather g;
+    g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.ldx = Cin; g.He = He; g.We = We; g.Ho = Ho; g.Wo = Wo;
+    g.k = k; g.stride = stride; g.pad = pad; g.shift = shift; g.parity = parity;
+    g.M = (int)M; g.Ktot = k * k * Cin;
+    g.div_howo = make_fastdiv((uint32_t)(Ho * Wo));
+    g.div_wo = make_fastdiv((uint32_t)Wo);
+    return g;
+}
+
+template <typename K> static int set_lds_limit(K kernel, int bytes, const char* who) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute(%d) failed: %s", who, bytes, hipGetErrorString(e));
+    return 0;
+}
+
+static bool nt_shape_ok(int Cin, int N, int64_t M, int dtype) {
+    const int piece = dtype == VAMD_BF16 ? 8 : 4;
+    const int kstep = dtype == VAMD_BF16 ? 64 : 32;
+    // a piece must not straddle two taps, and the tap state advances at most twice per K-step
+    return Cin % piece == 0 && 2 * Cin >= kstep && N % piece == 0 && M < (1ll << 26) && M > 0;
+}
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <typename T, int BN>
+static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
+                     void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
+    constexpr int LDS_PIPE = 2 * (kBM * kRowBytes + BN * kRowBytes);
+    constexpr int LDS_EPI = kBM * (BN + 4) * 4;
+    constexpr int LDS = LDS_PIPE > LDS_EPI ? LDS_PIPE : LDS_EPI;
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds_limit(conv_nt_mfma_kernel<T, BN>, LDS, "conv_nt_mfma");
+        if (rc) return rc;
+        configured = true;
+    }
+    const int m_tiles = (gp.M + kBM - 1) / kBM, n_tiles = (N + BN - 1) / BN;
+    dim3 grid(m_tiles * n_tiles, 1, batch);
+    hipLaunchKernelGGL((conv_nt_mfma_kernel<T, BN>), grid, dim3(256), LDS, st, gp, x, w, N, ldw, ldc, ep, y,
+                       m_tiles, n_tiles, sA, sB, sC);
+    VAMD_LAUNCH_OK("conv_nt_mfma");
+    return 0;
+}
+
+template <typename T>
+static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep,
+                  void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
+    if (N <= 64) return launch_nt<T, 64>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+    return launch_nt<T, 128>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+}
+
+bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype) {
+    return nt_shape_ok(g.Cin, g.Cout, g.M, dtype);
+}
+
+int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
+                  const float* temb, const void* res, const void* res2, void* y, hipStream_t st) {
+    Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, 0, g.M);
+    Epilogue ep{bias, temb, res, res2, 1.0f, 0};
+    if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
+    return run_nt<float>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
+}
+
+bool conv_dgrad_mfma_supported(const ConvGeom& g, int dtype) {
+    const int64_t rows = (int64_t)g.B * g.He * g.We;
+    return nt_shape_ok(g.Cout, g.Cin, rows, dtype);
+}
+
+size_t conv_dgrad_mfma_workspace(const ConvGeom& g, int dtype) {
+    if (!g.up) return 0;
+    return (size_t)g.B * g.He * g.We * g.Cin * (dtype == VAMD_BF16 ? 2 : 4);
+}
+
+template <typename T>
+__global__ void sumpool2x2_add_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ y,
+                                      int B, int H, int W, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)B * H * W * CV;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % CV);
+        int64_t p = idx / CV;
+        const int wq = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int64_t b = p / H;
+        const int64_t row = (int64_t)2 * W * C;
+        const T* s = x + ((b * 2 * H + 2 * h) * 2 * W + 2 * wq) * (int64_t)C + cv * VEC;
+        const Vec16<T> v0 = *reinterpret_cast<const Vec16<T>*>(s);
+        const Vec16<T> v1 = *reinterpret_cast<const Vec16<T>*>(s + C);
+        const Vec16<T> v2 = *reinterpret_cast<const Vec16<T>*>(s + row);
+        const Vec16<T> v3 = *reinterpret_cast<const Vec16<T>*>(s + row + C);
+        Vec16<T> o, a;
+        if (add) a = *reinterpret_cast<const Vec16<T>*>(add + idx * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float r = to_f(v0.v[e]) + to_f(v1.v[e]) + to_f(v2.v[e]) + to_f(v3.v[e]);
+            if (add) r += to_f(a.v[e]);
+            o.v[e] = from_f<T>(r);
+        }
+        *reinterpret_cast<Vec16<T>*>(y + idx * VEC) = o;
+    }
+}
+
+int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt, const void* add,
+                    void* dx, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    // The input gradient is itself a convolution over dY with the flipped, transposed filter:
+    //   stride 1: plain 3x3 pad 1 (or 1x1) over dY at the output resolution;
+    //   stride 2: dY is read through zero insertion (only even tap coordinates carry data);
+    //   upsample: stride-1 result at the upsampled resolution, then a 2x2 sum.
+    const int rowsH = g.up ? g.He : g.H, rowsW = g.up ? g.We : g.W;   // extents the GEMM rows enumerate
+    const int64_t rows = (int64_t)g.B * rowsH * rowsW;
+    const int dil = g.stride == 2 ? 1 : 0;
+    const int He = dil ? 2 * g.Ho - 1 : g.Ho, We = dil ? 2 * g.Wo - 1 : g.Wo;
+    const int padT = g.k - 1 - g.pad;
+    Gather gp = make_gather(g.Ho, g.Wo, g.Cout, He, We, rowsH, rowsW, g.k, 1, padT, dil, dil, rows);
+    void* out = dx;
+    const void* res = add;
+    if (g.up) {
+        if (!workspace || workspace_bytes < conv_dgrad_mfma_workspace(g, dtype))
+            return fail(VAMD_EINVAL, "conv_dgrad_mfma: upsample gradient needs %zu workspace bytes", conv_dgrad_mfma_workspace(g, dtype));
+        out = workspace;
+        res = nullptr;
+    }
+    Epilogue ep{nullptr, nullptr, res, nullptr, 1.0f, 0};
+    int rc = dtype == VAMD_BF16 ? run_nt<bf16_t>(gp, dy, wt, g.Cin, gp.Ktot, g.Cin, ep, out, 1, 0, 0, 0, st)
+                                : run_nt<float>(gp, dy, wt, g.Cin, gp.Ktot, g.Cin, ep, out, 1, 0, 0, 0, st);
+    if (rc) return rc;
+    if (g.up) {
+        const int64_t total = (int64_t)g.B * g.H * g.W * g.Cin;
+        VAMD_DISPATCH(dtype, "conv_dgrad_mfma", {
+            hipLaunchKernelGGL((sumpool2x2_add_kernel<T>), dim3(grid_for(total / Vec16<T>::N, 256)), dim3(256), 0, st,
+                               (const T*)workspace, (const T*)add, (T*)dx, g.B, g.H, g.W, g.Cin);
+        });
+        VAMD_LAUNCH_OK("sumpool2x2_add");
+    }
+    return 0;
+}
+
+static bool tn_shape_ok(int Cin, int N, int64_t M, int dtype) {
+    const int piece = dtype == VAMD_BF16 ? 8 : 4;
+    return Cin % piece == 0 && N % piece == 0 && M < (1ll << 26) && M > 0;
+}
+
+bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype) {
+    return tn_shape_ok(g.Cin, g.Cout, g.M, dtype);
+}
+
+template <typename T>
+static int launch_tn(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
+                     int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, hipStream_t st) {
+    constexpr int LDS = 2 * 2 * 16384;
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds_limit(conv_tn_mfma_kernel<T>, LDS, "conv_tn_mfma");
+        if (rc) return rc;
+        configured = true;
+    }
+    constexpr int KP = 16384 / (128 * sizeof(T));
+    const int n_tiles = (N + 127) / 128, f_tiles = (gp.Ktot + 127) / 128;
+    const int total_steps = (gp.M + KP - 1) / KP;
+    int slices = 1;
+    if (out_mode == 0) {
+        // enough workgroups to fill 256 CUs x 2, but at least 8 K-steps per slice
+        const int tiles = n_tiles * f_tiles * batch;
+        slices = (1024 + tiles - 1) / tiles;
+        const int max_slices = (total_steps + 7) / 8;
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+    }
+    const int steps_per = (total_steps + slices - 1) / slices;
+    slices = (total_steps + steps_per - 1) / steps_per;
+    dim3 grid(n_tiles * f_tiles, slices, batch);
+    hipLaunchKernelGGL((conv_tn_mfma_kernel<T>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
+                       f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha);
+    VAMD_LAUNCH_OK("conv_tn_mfma");
+    return 0;
+}
+
+int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, hipStream_t st) {
+    Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, 0, g.M);
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)g.Cout * gp.Ktot * sizeof(float), st);
+    if (e != hipSuccess) return fail((int)e, "conv_wgrad_mfma: memset failed: %s", hipGetErrorString(e));
+    if (dtype == VAMD_BF16)
+        return launch_tn<bf16_t>(gp, (const bf16_t*)dy, (const bf16_t*)x, g.Cout, g.Cout, gp.Ktot, dw, 1, 0, 0, 0, 0, nullptr, 1.f, st);
+    return launch_tn<float>(gp, (const float*)dy, (const float*)x, g.Cout, g.Cout, gp.Ktot, dw, 1, 0, 0, 0, 0, nullptr, 1.f, st);
+}
+
+// Batched products for the attention core on the same kernels.  Rows may be padded: lda/ldb/ldc
+// are the element strides between rows (multiples of 16 bytes); batch z starts at z*rows*ld.
+//   NT: C[z][m][n] = alpha * sum_k A[z][m][k] B[z][n][k]
+static bool ld_ok(int ld, int dtype) { return ld % (dtype == VAMD_BF16 ? 8 : 4) == 0; }
+
+bool bmm_nt_mfma_supported(int M, int N, int K, int lda, int ldb, int ldc, int dtype, int out_f32) {
+    const int piece = dtype == VAMD_BF16 ? 8 : 4;
+    const int kstep = dtype == VAMD_BF16 ? 64 : 32;
+    const int Kc = round_up(K, piece);
+    return ld_ok(lda, dtype) && ld_ok(ldb, dtype) && ldc % (out_f32 ? 4 : piece) == 0 && Kc <= lda && Kc <= ldb &&
+           round_up(N, piece) <= ldc && 2 * Kc >= kstep && M > 0 && M < (1 << 26);
+}
+
+int bmm_nt_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, int lda, int ldb,
+                int ldc, float alpha, int dtype, int out_f32, hipStream_t st) {
+    // columns K..round_up(K) of both operands must be finite padding (zeros) owned by the caller
+    const int Kc = round_up(K, dtype == VAMD_BF16 ? 8 : 4);
+    Gather gp = make_gather(1, M, Kc, 1, M, 1, M, 1, 1, 0, 0, 0, M);
+    gp.ldx = lda;
+    Epilogue ep{nullptr, nullptr, nullptr, nullptr, alpha, out_f32};
+    if (dtype == VAMD_BF16)
+        return run_nt<bf16_t>(gp, A, Bm, N, ldb, ldc, ep, C, batch, (int64_t)M * lda, (int64_t)N * ldb, (int64_t)M * ldc, st);
+    return run_nt<float>(gp, A, Bm, N, ldb, ldc, ep, C, batch, (int64_t)M * lda, (int64_t)N * ldb, (int64_t)M * ldc, st);
+}
+
+//   TN: C[z][m][n] = alpha * sum_k A[z][k][m] B[z][k][n]
+bool bmm_tn_mfma_supported(int M, int N, int K, int lda, int ldb, int ldc, int dtype) {
+    const int piece = dtype == VAMD_BF16 ? 8 : 4;
+    return ld_ok(lda, dtype) && ld_ok(ldb, dtype) && round_up(M, piece) <= lda && round_up(N, piece) <= ldb &&
+           N <= ldc && K > 0 && K < (1 << 26);
+}
+
+int bmm_tn_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, int lda, int ldb,
+                int ldc, float alpha, int dtype, hipStream_t st) {
+    // the reduction axis K plays the pixel axis; A's columns (M) play dY's channels, B's columns (N)
+    // play the gathered input's.  Padding columns up to the next 16-byte piece must be finite.
+    const int piece = dtype == VAMD_BF16 ? 8 : 4;
+    Gather gp = make_gather(1, K, round_up(N, piece), 1, K, 1, K, 1, 1, 0, 0, 0, K);
+    gp.ldx = ldb;
+    gp.Ktot = N;      // valid output columns
+    if (dtype == VAMD_BF16)
+        return launch_tn<bf16_t>(gp, (const bf16_t*)A, (const bf16_t*)Bm, M, lda, ldc, nullptr, batch, (int64_t)K * lda,
+                                 (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, st);
+    return launch_tn<float>(gp, (const float*)A, (const float*)Bm, M, lda, ldc, nullptr, batch, (int64_t)K * lda,
+                            (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, st);
+}
+
+}  // namespace vamd

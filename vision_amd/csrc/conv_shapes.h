@@ -1,0 +1,46 @@
+// Convolution geometry shared by the direct and MFMA kernels.
+#pragma once
+#include "common.h"
+
+namespace vamd {
+
+struct ConvGeom {
+    int B, H, W, Cin, Cout;   // H, W: stored input extents
+    int k, stride, pad, up;
+    int He, We;               // effective input extents (after the optional nearest 2x upsample)
+    int Ho, Wo;               // output extents
+    int64_t M;                // B * Ho * Wo output pixels
+};
+
+// Validates a vamd_conv_desc and fills `g`.  Returns 0 or a negative status (message set).
+int conv_geom(const vamd_conv_desc* d, ConvGeom* g, const char* who);
+
+// direct kernels (conv_direct.hip)
+int conv_fwd_direct(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
+                    const float* temb, const void* res, const void* res2, void* y, hipStream_t st);
+int conv_dgrad_direct(const ConvGeom& g, int dtype, const void* dy, const void* wt, const void* add,
+                      void* dx, hipStream_t st);
+int conv_wgrad_direct(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw,
+                      hipStream_t st);
+
+// MFMA implicit-GEMM kernels (conv_mfma.hip).  *_supported says whether the shape is covered.
+bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype);
+int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
+                  const float* temb, const void* res, const void* res2, void* y, hipStream_t st);
+bool conv_dgrad_mfma_supported(const ConvGeom& g, int dtype);
+size_t conv_dgrad_mfma_workspace(const ConvGeom& g, int dtype);
+int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt, const void* add,
+                    void* dx, void* workspace, size_t workspace_bytes, hipStream_t st);
+bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype);
+int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw,
+                    hipStream_t st);
+
+// batched products for the attention core on the MFMA kernels (rows may be padded: ld = row stride)
+bool bmm_nt_mfma_supported(int M, int N, int K, int lda, int ldb, int ldc, int dtype, int out_f32);
+int bmm_nt_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, int lda, int ldb,
+                int ldc, float alpha, int dtype, int out_f32, hipStream_t st);
+bool bmm_tn_mfma_supported(int M, int N, int K, int lda, int ldb, int ldc, int dtype);
+int bmm_tn_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N, int K, int lda, int ldb,
+                int ldc, float alpha, int dtype, hipStream_t st);
+
+}  // namespace vamd

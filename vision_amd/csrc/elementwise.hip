@@ -1,0 +1,581 @@
+// HBM-bound elementwise / small kernels: diffusion schedule + q_sample, L1 loss, sampler step,
+// layout converters, transpose, row softmax, time-embedding path, AdamW, weight repacking.
+#include "common.h"
+
+namespace vamd {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// acos(0.95f), acos(0.02f) evaluated in float like torch.acos on a float32 scalar tensor.
+__device__ __forceinline__ void schedule_of(float t, float& n, float& s) {
+    const float start = acosf(0.95f);
+    const float end = acosf(0.02f);
+    const float ang = start + t * (end - start);
+    s = cosf(ang);
+    n = sinf(ang);
+}
+
+__global__ void schedule_kernel(const float* __restrict__ t, float* n, float* s, float* n2, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float nn, ss;
+    schedule_of(t[b], nn, ss);
+    n[b] = nn;
+    s[b] = ss;
+    n2[b] = nn * nn;
+}
+
+// one thread per pixel: NCHW fp32 reads are coalesced per channel plane, NHWC writes are
+// C contiguous elements per thread.
+template <typename T>
+__global__ void qsample_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
+                               const float* __restrict__ t, T* __restrict__ xt, float* n_out,
+                               float* s_out, float* n2_out, int B, int C, int64_t HW) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / HW);
+        const int64_t hw = p - (int64_t)b * HW;
+        float n, s;
+        schedule_of(t[b], n, s);
+        if (hw == 0) {
+            n_out[b] = n;
+            s_out[b] = s;
+            n2_out[b] = n * n;
+        }
+        for (int c = 0; c < C; ++c) {
+            const int64_t src = ((int64_t)b * C + c) * HW + hw;
+            const float v = s * x0[src] + n * eps[src];
+            xt[p * C + c] = from_f<T>(v);
+        }
+    }
+}
+
+template <typename T>
+__global__ void l1_fwd_kernel(const T* __restrict__ pred, const float* __restrict__ eps,
+                              float* __restrict__ partial, int B, int C, int64_t HW) {
+    const int64_t total = (int64_t)B * HW;
+    float acc = 0.f;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / HW);
+        const int64_t hw = p - (int64_t)b * HW;
+        for (int c = 0; c < C; ++c)
+            acc += fabsf(to_f(pred[p * C + c]) - eps[((int64_t)b * C + c) * HW + hw]);
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void l1_finalize_kernel(const float* __restrict__ partial, int nchunk, double inv_numel,
+                                   float* loss) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nchunk; i += 64) acc += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (threadIdx.x == 0) loss[0] = (float)(acc * inv_numel);
+}
+
+template <typename T>
+__global__ void l1_bwd_kernel(const T* __restrict__ pred, const float* __restrict__ eps,
+                              const float* __restrict__ gout, T* __restrict__ dpred, int B, int C,
+                              int64_t HW, float inv_numel) {
+    const int64_t total = (int64_t)B * HW;
+    const float g = gout[0] * inv_numel;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / HW);
+        const int64_t hw = p - (int64_t)b * HW;
+        for (int c = 0; c < C; ++c) {
+            const float d = to_f(pred[p * C + c]) - eps[((int64_t)b * C + c) * HW + hw];
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);   // torch sign(): sign(0) = 0
+            dpred[p * C + c] = from_f<T>(g * sg);
+        }
+    }
+}
+
+template <typename T>
+__global__ void denoise_step_kernel(float* __restrict__ cur, const T* __restrict__ eps_hat,
+                                    const float* __restrict__ n, const float* __restrict__ s,
+                                    const float* __restrict__ n_next,
+                                    const float* __restrict__ s_next, T* __restrict__ next_in,
+                                    float* __restrict__ pred_images, int B, int C, int64_t HW) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / HW);
+        const int64_t hw = p - (int64_t)b * HW;
+        const float nb = n[b], sb = s[b], nn = n_next[b], sn = s_next[b];
+        for (int c = 0; c < C; ++c) {
+            const float e = to_f(eps_hat[p * C + c]);
+            const float x0h = (cur[p * C + c] - nb * e) / sb;
+            const float nx = sn * x0h + nn * e;
+            cur[p * C + c] = nx;
+            next_in[p * C + c] = from_f<T>(nx);
+            if (pred_images) pred_images[((int64_t)b * C + c) * HW + hw] = x0h;
+        }
+    }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y,
+                                    float* __restrict__ y32, int B, int C, int64_t HW) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / HW);
+        const int64_t hw = p - (int64_t)b * HW;
+        for (int c = 0; c < C; ++c) {
+            const float v = x[((int64_t)b * C + c) * HW + hw];
+            y[p * C + c] = from_f<T>(v);
+            if (y32) y32[p * C + c] = v;
+        }
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C,
+                                    int64_t HW) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / HW);
+        const int64_t hw = p - (int64_t)b * HW;
+        for (int c = 0; c < C; ++c) y[((int64_t)b * C + c) * HW + hw] = to_f(x[p * C + c]);
+    }
+}
+
+// [batch][R][C] -> [batch][C][R], 32x32 tiles through LDS (+1 pad).
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int C, int ldy) {
+    __shared__ float tile[32][33];
+    const int64_t base = (int64_t)blockIdx.z * R * C;
+    const int64_t obase = (int64_t)blockIdx.z * C * ldy;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < R && c < C) tile[i][tx] = to_f(x[base + (int64_t)r * C + c]);
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) y[obase + (int64_t)c * ldy + r] = from_f<T>(tile[tx][i]);
+    }
+}
+
+// one wave per row; x fp32 -> p in T
+template <typename T>
+__global__ void softmax_rows_kernel(const float* __restrict__ x, T* __restrict__ y, int64_t rows,
+                                    int cols, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < rows; r += nwave) {
+        const float* xr = x + r * ld;
+        float m = -INFINITY;
+        for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int c = lane; c < cols; c += 64) sum += expf(xr[c] - m);
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int c = lane; c < cols; c += 64) y[r * ld + c] = from_f<T>(expf(xr[c] - m) * inv);
+    }
+}
+
+template <typename T>
+__global__ void softmax_rows_bwd_kernel(const T* __restrict__ p, const float* __restrict__ dp,
+                                        T* __restrict__ ds, int64_t rows, int cols, int ld, float alpha) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < rows; r += nwave) {
+        const T* pr = p + r * ld;
+        const float* dr = dp + r * ld;
+        float dot = 0.f;
+        for (int c = lane; c < cols; c += 64) dot += to_f(pr[c]) * dr[c];
+        dot = wave_sum(dot);
+        for (int c = lane; c < cols; c += 64)
+            ds[r * ld + c] = from_f<T>(alpha * to_f(pr[c]) * (dr[c] - dot));
+    }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
+                           int64_t nvec, int64_t n) {
+    using V = Vec16<T>;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        V va = reinterpret_cast<const V*>(a)[i], vb = reinterpret_cast<const V*>(b)[i], vo;
+#pragma unroll
+        for (int j = 0; j < V::N; ++j) vo.v[j] = from_f<T>(to_f(va.v[j]) + to_f(vb.v[j]));
+        reinterpret_cast<V*>(y)[i] = vo;
+    }
+    for (int64_t i = nvec * V::N + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = from_f<T>(to_f(a[i]) + to_f(b[i]));
+}
+
+__global__ void timeembed_kernel(const float* __restrict__ t, const float* __restrict__ w,
+                                 float* __restrict__ emb, int B, int dim) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i - b * half;
+    const float a = w[j] * t[b];
+    emb[b * dim + j] = sinf(a);
+    emb[b * dim + half + j] = cosf(a);
+}
+
+// thread per (b, o)
+__global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                  const float* __restrict__ bias, float* __restrict__ y, int B,
+                                  int I, int O, int act_in, float slope) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * O) return;
+    const int b = idx / O, o = idx - b * O;
+    const float* xr = x + (int64_t)b * I;
+    const float* wr = W + (int64_t)o * I;
+    float acc = 0.f;
+    for (int i = 0; i < I; ++i) {
+        float v = xr[i];
+        if (act_in) v = leaky(v, slope);
+        acc = fmaf(v, wr[i], acc);
+    }
+    y[idx] = acc + (bias ? bias[o] : 0.f);
+}
+
+// thread per (b, i): dx[b][i] = act'(x) * sum_o dy[b][o] W[o][i]
+__global__ void linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                     const float* __restrict__ dy, float* __restrict__ dx, int B,
+                                     int I, int O, int act_in, float slope, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * I) return;
+    const int b = idx / I, i = idx - b * I;
+    float acc = 0.f;
+    for (int o = 0; o < O; ++o) acc = fmaf(dy[(int64_t)b * O + o], W[(int64_t)o * I + i], acc);
+    if (act_in && !(x[idx] > 0.f)) acc *= slope;
+    dx[idx] = accumulate ? dx[idx] + acc : acc;
+}
+
+// thread per (o, i): dW[o][i] = sum_b dy[b][o] act(x[b][i]); i == 0 also writes dbias[o]
+__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                     float* __restrict__ dW, float* __restrict__ dbias, int B,
+                                     int I, int O, int act_in, float slope) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= O * I) return;
+    const int o = idx / I, i = idx - o * I;
+    float acc = 0.f, accb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float v = x[(int64_t)b * I + i];
+        if (act_in) v = leaky(v, slope);
+        const float g = dy[(int64_t)b * O + o];
+        acc = fmaf(g, v, acc);
+        accb += g;
+    }
+    dW[idx] = acc;
+    if (i == 0 && dbias) dbias[o] = accb;
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                             float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                             const float* __restrict__ lr_dev, float beta1, float beta2, float eps,
+                             float wd, float bc1, float rsqrt_bc2, float gscale) {
+    if (lr_dev) lr = lr_dev[0];
+    const float step_size = lr / bc1;
+    const float decay = 1.f - lr * wd;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nvec = n >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = G[j] * gscale;
+            M[j] = beta1 * M[j] + (1.f - beta1) * gr;
+            V[j] = beta2 * V[j] + (1.f - beta2) * gr * gr;
+            const float denom = sqrtf(V[j]) * rsqrt_bc2 + eps;
+            P[j] = P[j] * decay - step_size * (M[j] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (int64_t i = (nvec << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gr = g[i] * gscale;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gr;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] * decay - step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + eps));
+    }
+}
+
+// w [O][I][k][k] fp32 -> wf [O][k][k][I], wd [I][k][k][O] with kernel axes flipped
+template <typename T>
+__global__ void repack_weight_kernel(const float* __restrict__ w, T* __restrict__ wf,
+                                     T* __restrict__ wd, int O, int I, int k) {
+    const int64_t total = (int64_t)O * I * k * k;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        // idx enumerates the destination wf layout (o, r, s, i) so writes are coalesced
+        const int i = (int)(idx % I);
+        int64_t rest = idx / I;
+        const int s = (int)(rest % k); rest /= k;
+        const int r = (int)(rest % k);
+        const int o = (int)(rest / k);
+        const float v = w[(((int64_t)o * I + i) * k + r) * k + s];
+        wf[idx] = from_f<T>(v);
+        if (wd) wd[(((int64_t)i * k + (k - 1 - r)) * k + (k - 1 - s)) * O + o] = from_f<T>(v);
+    }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwk, float* __restrict__ dw, int O,
+                                    int I, int k) {
+    const int64_t total = (int64_t)O * I * k * k;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % I);
+        int64_t rest = idx / I;
+        const int s = (int)(rest % k); rest /= k;
+        const int r = (int)(rest % k);
+        const int o = (int)(rest / k);
+        dw[(((int64_t)o * I + i) * k + r) * k + s] = dwk[idx];
+    }
+}
+
+}  // namespace vamd
+
+using namespace vamd;
+
+extern "C" {
+
+const char* vamd_last_error(void) { return g_err; }
+int vamd_version(void) { return 1; }
+
+int vamd_schedule(const float* t, float* n, float* s, float* n2, int B, void* stream) {
+    VAMD_REQUIRE(t && n && s && n2 && B > 0, "vamd_schedule: null pointer or B <= 0");
+    hipLaunchKernelGGL(schedule_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), t, n, s, n2, B);
+    VAMD_LAUNCH_OK("vamd_schedule");
+    return 0;
+}
+
+int vamd_qsample(const float* x0, const float* eps, const float* t, void* xt, float* n, float* s,
+                 float* n2, int B, int C, int H, int W, int dtype, void* stream) {
+    VAMD_REQUIRE(x0 && eps && t && xt && n && s && n2, "vamd_qsample: null pointer");
+    VAMD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "vamd_qsample: bad shape %d %d %d %d", B, C, H, W);
+    const int64_t HW = (int64_t)H * W;
+    VAMD_DISPATCH(dtype, "vamd_qsample", {
+        hipLaunchKernelGGL(qsample_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
+                           as_stream(stream), x0, eps, t, (T*)xt, n, s, n2, B, C, HW);
+    });
+    VAMD_LAUNCH_OK("vamd_qsample");
+    return 0;
+}
+
+int vamd_l1_chunks(int64_t npix) { return grid_for(npix, 256, 1024); }
+
+int vamd_l1_loss_fwd(const void* pred, const float* eps, float* partial, float* loss, int B, int C,
+                     int H, int W, int dtype, void* stream) {
+    VAMD_REQUIRE(pred && eps && partial && loss, "vamd_l1_loss_fwd: null pointer");
+    VAMD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "vamd_l1_loss_fwd: bad shape");
+    const int64_t HW = (int64_t)H * W;
+    const int nchunk = vamd_l1_chunks(B * HW);
+    VAMD_DISPATCH(dtype, "vamd_l1_loss_fwd", {
+        hipLaunchKernelGGL(l1_fwd_kernel<T>, dim3(nchunk), dim3(256), 0, as_stream(stream),
+                           (const T*)pred, eps, partial, B, C, HW);
+    });
+    hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), partial, nchunk,
+                       1.0 / ((double)B * C * HW), loss);
+    VAMD_LAUNCH_OK("vamd_l1_loss_fwd");
+    return 0;
+}
+
+int vamd_l1_loss_bwd(const void* pred, const float* eps, const float* gout, void* dpred, int B,
+                     int C, int H, int W, int dtype, void* stream) {
+    VAMD_REQUIRE(pred && eps && gout && dpred, "vamd_l1_loss_bwd: null pointer");
+    VAMD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "vamd_l1_loss_bwd: bad shape");
+    const int64_t HW = (int64_t)H * W;
+    VAMD_DISPATCH(dtype, "vamd_l1_loss_bwd", {
+        hipLaunchKernelGGL(l1_bwd_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
+                           as_stream(stream), (const T*)pred, eps, gout, (T*)dpred, B, C, HW,
+                           (float)(1.0 / ((double)B * C * HW)));
+    });
+    VAMD_LAUNCH_OK("vamd_l1_loss_bwd");
+    return 0;
+}
+
+int vamd_denoise_step(float* cur, const void* eps_hat, const float* n, const float* s,
+                      const float* n_next, const float* s_next, void* next_in, float* pred_images,
+                      int B, int C, int H, int W, int dtype, void* stream) {
+    VAMD_REQUIRE(cur && eps_hat && n && s && n_next && s_next && next_in, "vamd_denoise_step: null pointer");
+    VAMD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "vamd_denoise_step: bad shape");
+    const int64_t HW = (int64_t)H * W;
+    VAMD_DISPATCH(dtype, "vamd_denoise_step", {
+        hipLaunchKernelGGL(denoise_step_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
+                           as_stream(stream), cur, (const T*)eps_hat, n, s, n_next, s_next,
+                           (T*)next_in, pred_images, B, C, HW);
+    });
+    VAMD_LAUNCH_OK("vamd_denoise_step");
+    return 0;
+}
+
+int vamd_nchw_to_nhwc(const float* x, void* y, float* y32, int B, int C, int H, int W, int dtype,
+                      void* stream) {
+    VAMD_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "vamd_nchw_to_nhwc: bad argument");
+    const int64_t HW = (int64_t)H * W;
+    VAMD_DISPATCH(dtype, "vamd_nchw_to_nhwc", {
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
+                           as_stream(stream), x, (T*)y, y32, B, C, HW);
+    });
+    VAMD_LAUNCH_OK("vamd_nchw_to_nhwc");
+    return 0;
+}
+
+int vamd_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int dtype, void* stream) {
+    VAMD_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "vamd_nhwc_to_nchw: bad argument");
+    const int64_t HW = (int64_t)H * W;
+    VAMD_DISPATCH(dtype, "vamd_nhwc_to_nchw", {
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
+                           as_stream(stream), (const T*)x, y, B, C, HW);
+    });
+    VAMD_LAUNCH_OK("vamd_nhwc_to_nchw");
+    return 0;
+}
+
+int vamd_transpose(const void* x, void* y, int batch, int R, int C, int ldy, int dtype, void* stream) {
+    VAMD_REQUIRE(x && y && batch > 0 && R > 0 && C > 0 && ldy >= R, "vamd_transpose: bad argument");
+    VAMD_REQUIRE(batch <= 65535 && (R + 31) / 32 <= 65535, "vamd_transpose: grid too large");
+    dim3 grid((C + 31) / 32, (R + 31) / 32, batch);
+    VAMD_DISPATCH(dtype, "vamd_transpose", {
+        hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, as_stream(stream), (const T*)x,
+                           (T*)y, R, C, ldy);
+    });
+    VAMD_LAUNCH_OK("vamd_transpose");
+    return 0;
+}
+
+int vamd_softmax_rows(const float* x, void* y, int64_t rows, int cols, int ld, int dtype, void* stream) {
+    VAMD_REQUIRE(x && y && rows > 0 && cols > 0 && ld >= cols, "vamd_softmax_rows: bad argument");
+    VAMD_DISPATCH(dtype, "vamd_softmax_rows", {
+        hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0,
+                           as_stream(stream), x, (T*)y, rows, cols, ld);
+    });
+    VAMD_LAUNCH_OK("vamd_softmax_rows");
+    return 0;
+}
+
+int vamd_softmax_rows_bwd(const void* p, const float* dp, void* ds, int64_t rows, int cols, int ld,
+                          float alpha, int dtype, void* stream) {
+    VAMD_REQUIRE(p && dp && ds && rows > 0 && cols > 0 && ld >= cols, "vamd_softmax_rows_bwd: bad argument");
+    VAMD_DISPATCH(dtype, "vamd_softmax_rows_bwd", {
+        hipLaunchKernelGGL(softmax_rows_bwd_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0,
+                           as_stream(stream), (const T*)p, dp, (T*)ds, rows, cols, ld, alpha);
+    });
+    VAMD_LAUNCH_OK("vamd_softmax_rows_bwd");
+    return 0;
+}
+
+int vamd_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {
+    VAMD_REQUIRE(a && b && y && n > 0, "vamd_add: bad argument");
+    VAMD_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ((uintptr_t)y % 16 == 0),
+                 "vamd_add: pointers must be 16-byte aligned");
+    VAMD_DISPATCH(dtype, "vamd_add", {
+        const int64_t nvec = n / Vec16<T>::N;
+        hipLaunchKernelGGL(add_kernel<T>, dim3(grid_for(nvec > 0 ? nvec : 1, 256)), dim3(256), 0,
+                           as_stream(stream), (const T*)a, (const T*)b, (T*)y, nvec, n);
+    });
+    VAMD_LAUNCH_OK("vamd_add");
+    return 0;
+}
+
+int vamd_timeembed(const float* t, const float* angular_speeds, float* emb, int B, int dim,
+                   void* stream) {
+    VAMD_REQUIRE(t && angular_speeds && emb && B > 0 && dim > 0 && dim % 2 == 0,
+                 "vamd_timeembed: bad argument (dim must be even)");
+    const int total = B * (dim / 2);
+    hipLaunchKernelGGL(timeembed_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
+                       t, angular_speeds, emb, B, dim);
+    VAMD_LAUNCH_OK("vamd_timeembed");
+    return 0;
+}
+
+int vamd_linear_fwd(const float* x, const float* W, const float* bias, float* y, int B, int I,
+                    int O, int act_in, float slope, void* stream) {
+    VAMD_REQUIRE(x && W && y && B > 0 && I > 0 && O > 0, "vamd_linear_fwd: bad argument");
+    const int total = B * O;
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
+                       x, W, bias, y, B, I, O, act_in, slope);
+    VAMD_LAUNCH_OK("vamd_linear_fwd");
+    return 0;
+}
+
+int vamd_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW,
+                    float* dbias, int B, int I, int O, int act_in, float slope, int accumulate_dx,
+                    void* stream) {
+    VAMD_REQUIRE(x && W && dy && dW && B > 0 && I > 0 && O > 0, "vamd_linear_bwd: bad argument");
+    if (dx) {
+        const int total = B * I;
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                           as_stream(stream), x, W, dy, dx, B, I, O, act_in, slope, accumulate_dx);
+    }
+    const int total = O * I;
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                       as_stream(stream), x, dy, dW, dbias, B, I, O, act_in, slope);
+    VAMD_LAUNCH_OK("vamd_linear_bwd");
+    return 0;
+}
+
+int vamd_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+               const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+               int step, float grad_scale, void* stream) {
+    VAMD_REQUIRE(p && g && m && v && n > 0 && step >= 1, "vamd_adamw: bad argument");
+    VAMD_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                     ((uintptr_t)v % 16 == 0), "vamd_adamw: arenas must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0,
+                       as_stream(stream), p, g, m, v, n, lr, lr_dev, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+    VAMD_LAUNCH_OK("vamd_adamw");
+    return 0;
+}
+
+int vamd_repack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int ksize, int dtype,
+                       void* stream) {
+    VAMD_REQUIRE(w && wf && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3),
+                 "vamd_repack_weight: bad argument");
+    const int64_t total = (int64_t)Cout * Cin * ksize * ksize;
+    VAMD_DISPATCH(dtype, "vamd_repack_weight", {
+        hipLaunchKernelGGL(repack_weight_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                           as_stream(stream), w, (T*)wf, (T*)wd, Cout, Cin, ksize);
+    });
+    VAMD_LAUNCH_OK("vamd_repack_weight");
+    return 0;
+}
+
+int vamd_unpack_wgrad(const float* dwk, float* dw, int Cout, int Cin, int ksize, void* stream) {
+    VAMD_REQUIRE(dwk && dw && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3),
+                 "vamd_unpack_wgrad: bad argument");
+    const int64_t total = (int64_t)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                       as_stream(stream), dwk, dw, Cout, Cin, ksize);
+    VAMD_LAUNCH_OK("vamd_unpack_wgrad");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,497 @@
+// BatchNorm / GroupNorm statistics, fused scale-shift-LeakyReLU(-dropout) apply, and their backward.
+// All tensors are viewed as [G][R][C] (channel innermost): BatchNorm has G = 1, R = B*H*W;
+// GroupNorm and per-image sums have G = B, R = H*W.  HBM-bound: every kernel reads its
+// inputs once with 16-byte accesses and reduces in registers -> LDS -> one partial row per block.
+#include "common.h"
+
+namespace vamd {
+
+constexpr int kStatsBlock = 256;
+constexpr int kStatsRowsPerChunk = 256;
+constexpr int kStatsMaxChunks = 512;
+
+static inline int stats_chunks(int64_t R) {
+    int64_t n = (R + kStatsRowsPerChunk - 1) / kStatsRowsPerChunk;
+    if (n < 1) n = 1;
+    if (n > kStatsMaxChunks) n = kStatsMaxChunks;
+    return (int)n;
+}
+
+struct NormBwdArgs {
+    const void* dy;
+    const void* mask;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* rstd;
+    float slope;
+};
+
+// MODE 0: accumulates (x, x*x).  MODE 1: accumulates (gz, gz*xhat) for the backward pass.
+// Thread layout: tc = C/VEC lanes across channels, tr = 256/tc lanes across rows.
+template <typename T, int VEC, int MODE>
+__global__ void __launch_bounds__(kStatsBlock)
+chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ partial, int64_t R,
+                  int C, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [tr][C][2]
+    const int g = blockIdx.y, chunk = blockIdx.x;
+    const int cvec = C / VEC;
+    const int tc = cvec;                       // host guarantees cvec <= 256
+    const int tr = kStatsBlock / tc;
+    const int rl = threadIdx.x / tc, cl = threadIdx.x - rl * tc;
+    const int64_t rows_per = (R + nchunk - 1) / nchunk;
+    const int64_t r0 = (int64_t)chunk * rows_per;
+    int64_t r1 = r0 + rows_per;
+    if (r1 > R) r1 = R;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
+    if (rl < tr) {
+        const int c0 = cl * VEC;
+        float sc[VEC], sh[VEC], mu[VEC], rs[VEC];
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                sc[j] = a.scale[(int64_t)g * C + c0 + j];
+                sh[j] = a.shift[(int64_t)g * C + c0 + j];
+                mu[j] = a.mean[(int64_t)g * C + c0 + j];
+                rs[j] = a.rstd[(int64_t)g * C + c0 + j];
+            }
+        }
+        const T* dy = (const T*)a.dy;
+        const T* mk = (const T*)a.mask;
+        for (int64_t r = r0 + rl; r < r1; r += tr) {
+            const int64_t off = ((int64_t)g * R + r) * C + c0;
+            alignas(16) T xv[VEC]; alignas(16) T dv[VEC]; alignas(16) T mv[VEC];
+            if (VEC > 1) {
+                *reinterpret_cast<Vec16<T>*>(xv) = *reinterpret_cast<const Vec16<T>*>(x + off);
+                if (MODE == 1) {
+                    *reinterpret_cast<Vec16<T>*>(dv) = *reinterpret_cast<const Vec16<T>*>(dy + off);
+                    if (mk) *reinterpret_cast<Vec16<T>*>(mv) = *reinterpret_cast<const Vec16<T>*>(mk + off);
+                }
+            } else {
+                xv[0] = x[off];
+                if (MODE == 1) {
+                    dv[0] = dy[off];
+                    if (mk) mv[0] = mk[off];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xf = to_f(xv[j]);
+                if (MODE == 0) {
+                    s1[j] += xf;
+                    s2[j] = fmaf(xf, xf, s2[j]);
+                } else {
+                    const float z = fmaf(xf, sc[j], sh[j]);
+                    float gz = to_f(dv[j]);
+                    if (mk) gz *= to_f(mv[j]);
+                    if (!(z > 0.f)) gz *= a.slope;
+                    const float xh = (xf - mu[j]) * rs[j];
+                    s1[j] += gz;
+                    s2[j] = fmaf(gz, xh, s2[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            red[((int64_t)rl * C + c0 + j) * 2 + 0] = s1[j];
+            red[((int64_t)rl * C + c0 + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    float* out = partial + ((int64_t)g * nchunk + chunk) * C * 2;
+    for (int i = threadIdx.x; i < C * 2; i += kStatsBlock) {
+        float acc = 0.f;
+        for (int r = 0; r < tr; ++r) acc += red[(int64_t)r * C * 2 + i];
+        out[i] = acc;
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nchunk, int C,
+                                   double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean,
+                                   float* running_var, int64_t* nbt, float momentum, float eps,
+                                   int training, float* scale, float* shift, float* mean,
+                                   float* rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mu, var;
+    if (training) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            s1 += (double)partial[((int64_t)k * C + c) * 2 + 0];
+            s2 += (double)partial[((int64_t)k * C + c) * 2 + 1];
+        }
+        const double m = s1 / count;
+        double v = s2 / count - m * m;
+        if (v < 0.0) v = 0.0;
+        mu = (float)m;
+        var = (float)v;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+        if (c == 0 && nbt) nbt[0] += 1;
+    } else {
+        mu = running_mean[c];
+        var = running_var[c];
+    }
+    const float r = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * r;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
+    mean[c] = mu;
+    rstd[c] = r;
+}
+
+// thread per (b, group)
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
+                                   int groups, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float* scale,
+                                   float* shift, float* mean, float* rstd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * groups) return;
+    const int b = idx / groups, gr = idx - b * groups;
+    const int cpg = C / groups;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k)
+        for (int j = 0; j < cpg; ++j) {
+            const int c = gr * cpg + j;
+            s1 += (double)partial[(((int64_t)b * nchunk + k) * C + c) * 2 + 0];
+            s2 += (double)partial[(((int64_t)b * nchunk + k) * C + c) * 2 + 1];
+        }
+    const double m = s1 / count;
+    double v = s2 / count - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mu = (float)m;
+    const float r = 1.0f / sqrtf((float)v + eps);
+    for (int j = 0; j < cpg; ++j) {
+        const int c = gr * cpg + j;
+        const float sc = gamma[c] * r;
+        scale[(int64_t)b * C + c] = sc;
+        shift[(int64_t)b * C + c] = beta[c] - mu * sc;
+        mean[(int64_t)b * C + c] = mu;
+        rstd[(int64_t)b * C + c] = r;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunk, int C,
+                                       double count, const float* __restrict__ scale,
+                                       float* dgamma, float* dbeta, float* cA, float* cB,
+                                       float* cC) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s1 += (double)partial[((int64_t)k * C + c) * 2 + 0];
+        s2 += (double)partial[((int64_t)k * C + c) * 2 + 1];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    const double sc = (double)scale[c];
+    cA[c] = (float)sc;
+    cB[c] = (float)(-sc * s1 / count);
+    cC[c] = (float)(-sc * s2 / count);
+}
+
+// thread per (b, group): coefficients
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
+                                   int groups, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ rstd, float* cA, float* cB, float* cC) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * groups) return;
+    const int b = idx / groups, gr = idx - b * groups;
+    const int cpg = C / groups;
+    double m1 = 0.0, m2 = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+        const int c = gr * cpg + j;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            s1 += (double)partial[(((int64_t)b * nchunk + k) * C + c) * 2 + 0];
+            s2 += (double)partial[(((int64_t)b * nchunk + k) * C + c) * 2 + 1];
+        }
+        m1 += (double)gamma[c] * s1;
+        m2 += (double)gamma[c] * s2;
+    }
+    m1 /= count;
+    m2 /= count;
+    for (int j = 0; j < cpg; ++j) {
+        const int c = gr * cpg + j;
+        const double r = (double)rstd[(int64_t)b * C + c];
+        cA[(int64_t)b * C + c] = (float)(r * (double)gamma[c]);
+        cB[(int64_t)b * C + c] = (float)(-r * m1);
+        cC[(int64_t)b * C + c] = (float)(-r * m2);
+    }
+}
+
+// thread per c: per_g[g][c] = sum_chunk comp, total[c] = sum_g; comp 0 -> out0, comp 1 -> out1
+__global__ void sum_over_g_kernel(const float* __restrict__ partial, int nchunk, int G, int C,
+                                  float* per_g0, float* total0, float* total1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double t0 = 0.0, t1 = 0.0;
+    for (int g = 0; g < G; ++g) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            s0 += (double)partial[(((int64_t)g * nchunk + k) * C + c) * 2 + 0];
+            s1 += (double)partial[(((int64_t)g * nchunk + k) * C + c) * 2 + 1];
+        }
+        if (per_g0) per_g0[(int64_t)g * C + c] = (float)s0;
+        t0 += s0;
+        t1 += s1;
+    }
+    if (total0) total0[c] = (float)t0;
+    if (total1) total1[c] = (float)t1;
+}
+
+template <typename T, int VEC>
+__global__ void scale_shift_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, const T* __restrict__ mask,
+                                       float slope, T* __restrict__ y, int64_t RC, int C,
+                                       int64_t nvec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const int64_t e = i * VEC;
+        const int64_t g = e / RC;
+        const int c = (int)(e % C);
+        const float* sc = scale + g * C + c;
+        const float* sh = shift + g * C + c;
+        alignas(16) T xv[VEC]; alignas(16) T mv[VEC]; alignas(16) T yv[VEC];
+        if (VEC > 1) {
+            *reinterpret_cast<Vec16<T>*>(xv) = *reinterpret_cast<const Vec16<T>*>(x + e);
+            if (mask) *reinterpret_cast<Vec16<T>*>(mv) = *reinterpret_cast<const Vec16<T>*>(mask + e);
+        } else {
+            xv[0] = x[e];
+            if (mask) mv[0] = mask[e];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float z = leaky(fmaf(to_f(xv[j]), sc[j], sh[j]), slope);
+            if (mask) z *= to_f(mv[j]);
+            yv[j] = from_f<T>(z);
+        }
+        if (VEC > 1) *reinterpret_cast<Vec16<T>*>(y + e) = *reinterpret_cast<Vec16<T>*>(yv);
+        else y[e] = yv[0];
+    }
+}
+
+struct NormApplyArgs {
+    const void* dy; const void* x; const void* mask;
+    const float* scale; const float* shift; const float* mean; const float* rstd;
+    const float* cA; const float* cB; const float* cC;
+    const void* add; const void* add2;
+    float slope;
+};
+
+template <typename T, int VEC>
+__global__ void norm_bwd_apply_kernel(NormApplyArgs a, T* __restrict__ dx, int64_t RC, int C,
+                                      int64_t nvec) {
+    const T* dy = (const T*)a.dy; const T* x = (const T*)a.x; const T* mask = (const T*)a.mask;
+    const T* add = (const T*)a.add; const T* add2 = (const T*)a.add2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const int64_t e = i * VEC;
+        const int64_t gc = (e / RC) * C + (e % C);
+        alignas(16) T xv[VEC]; alignas(16) T dv[VEC]; alignas(16) T mv[VEC]; alignas(16) T av[VEC]; alignas(16) T a2v[VEC]; alignas(16) T ov[VEC];
+        if (VEC > 1) {
+            *reinterpret_cast<Vec16<T>*>(xv) = *reinterpret_cast<const Vec16<T>*>(x + e);
+            *reinterpret_cast<Vec16<T>*>(dv) = *reinterpret_cast<const Vec16<T>*>(dy + e);
+            if (mask) *reinterpret_cast<Vec16<T>*>(mv) = *reinterpret_cast<const Vec16<T>*>(mask + e);
+            if (add) *reinterpret_cast<Vec16<T>*>(av) = *reinterpret_cast<const Vec16<T>*>(add + e);
+            if (add2) *reinterpret_cast<Vec16<T>*>(a2v) = *reinterpret_cast<const Vec16<T>*>(add2 + e);
+        } else {
+            xv[0] = x[e]; dv[0] = dy[e];
+            if (mask) mv[0] = mask[e];
+            if (add) av[0] = add[e];
+            if (add2) a2v[0] = add2[e];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xf = to_f(xv[j]);
+            const float z = fmaf(xf, a.scale[gc + j], a.shift[gc + j]);
+            float gz = to_f(dv[j]);
+            if (mask) gz *= to_f(mv[j]);
+            if (!(z > 0.f)) gz *= a.slope;
+            const float xh = (xf - a.mean[gc + j]) * a.rstd[gc + j];
+            float r = fmaf(a.cA[gc + j], gz, fmaf(a.cC[gc + j], xh, a.cB[gc + j]));
+            if (add) r += to_f(av[j]);
+            if (add2) r += to_f(a2v[j]);
+            ov[j] = from_f<T>(r);
+        }
+        if (VEC > 1) *reinterpret_cast<Vec16<T>*>(dx + e) = *reinterpret_cast<Vec16<T>*>(ov);
+        else dx[e] = ov[0];
+    }
+}
+
+template <typename T, int MODE>
+static int launch_stats(const char* name, const T* x, NormBwdArgs a, float* partial, int G,
+                        int64_t R, int C, hipStream_t st) {
+    constexpr int VEC = Vec16<T>::N;
+    const int nchunk = stats_chunks(R);
+    dim3 grid(nchunk, G);
+    const bool vec = (C % VEC == 0) && (C / VEC <= kStatsBlock);
+    if (vec) {
+        const int tr = kStatsBlock / (C / VEC);
+        const size_t lds = (size_t)tr * C * 2 * sizeof(float);
+        hipLaunchKernelGGL((chan_stats_kernel<T, VEC, MODE>), grid, dim3(kStatsBlock), lds, st, x, a,
+                           partial, R, C, nchunk);
+    } else {
+        if (C > kStatsBlock) return fail(VAMD_EUNSUPPORTED, "%s: C=%d not a multiple of %d and > 256", name, C, VEC);
+        const int tr = kStatsBlock / C;
+        const size_t lds = (size_t)tr * C * 2 * sizeof(float);
+        hipLaunchKernelGGL((chan_stats_kernel<T, 1, MODE>), grid, dim3(kStatsBlock), lds, st, x, a,
+                           partial, R, C, nchunk);
+    }
+    return 0;
+}
+
+}  // namespace vamd
+
+using namespace vamd;
+
+extern "C" {
+
+int vamd_stats_chunks(int64_t R) { return stats_chunks(R); }
+
+int vamd_chan_stats(const void* x, float* partial, int G, int64_t R, int C, int dtype, void* stream) {
+    VAMD_REQUIRE(x && partial && G > 0 && G <= 65535 && R > 0 && C > 0, "vamd_chan_stats: bad argument");
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0, "vamd_chan_stats: x must be 16-byte aligned");
+    NormBwdArgs a{};
+    VAMD_DISPATCH(dtype, "vamd_chan_stats", {
+        int rc = launch_stats<T, 0>("vamd_chan_stats", (const T*)x, a, partial, G, R, C, as_stream(stream));
+        if (rc) return rc;
+    });
+    VAMD_LAUNCH_OK("vamd_chan_stats");
+    return 0;
+}
+
+int vamd_norm_bwd_stats(const void* dy, const void* x, const void* mask, const float* scale,
+                        const float* shift, const float* mean, const float* rstd, float slope,
+                        float* partial, int G, int64_t R, int C, int dtype, void* stream) {
+    VAMD_REQUIRE(dy && x && scale && shift && mean && rstd && partial, "vamd_norm_bwd_stats: null pointer");
+    VAMD_REQUIRE(G > 0 && G <= 65535 && R > 0 && C > 0, "vamd_norm_bwd_stats: bad shape");
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)mask % 16 == 0,
+                 "vamd_norm_bwd_stats: tensors must be 16-byte aligned");
+    NormBwdArgs a{dy, mask, scale, shift, mean, rstd, slope};
+    VAMD_DISPATCH(dtype, "vamd_norm_bwd_stats", {
+        int rc = launch_stats<T, 1>("vamd_norm_bwd_stats", (const T*)x, a, partial, G, R, C, as_stream(stream));
+        if (rc) return rc;
+    });
+    VAMD_LAUNCH_OK("vamd_norm_bwd_stats");
+    return 0;
+}
+
+int vamd_bn_finalize(const float* partial, int nchunk, int C, int64_t count, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float momentum, float eps, int training,
+                     float* scale, float* shift, float* mean, float* rstd, void* stream) {
+    VAMD_REQUIRE(gamma && beta && scale && shift && mean && rstd && C > 0, "vamd_bn_finalize: null pointer");
+    VAMD_REQUIRE(training ? (partial && nchunk > 0 && count > 0) : (running_mean && running_var),
+                 "vamd_bn_finalize: training needs partial sums, eval needs running statistics");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream),
+                       partial, nchunk, C, (double)count, gamma, beta, running_mean, running_var,
+                       num_batches_tracked, momentum, eps, training, scale, shift, mean, rstd);
+    VAMD_LAUNCH_OK("vamd_bn_finalize");
+    return 0;
+}
+
+int vamd_gn_finalize(const float* partial, int nchunk, int B, int C, int groups, int64_t HW,
+                     const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                     float* mean, float* rstd, void* stream) {
+    VAMD_REQUIRE(partial && gamma && beta && scale && shift && mean && rstd, "vamd_gn_finalize: null pointer");
+    VAMD_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && HW > 0 && nchunk > 0,
+                 "vamd_gn_finalize: bad shape (C=%d groups=%d)", C, groups);
+    const int total = B * groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 63) / 64), dim3(64), 0, as_stream(stream),
+                       partial, nchunk, B, C, groups, (double)HW * (C / groups), gamma, beta, eps,
+                       scale, shift, mean, rstd);
+    VAMD_LAUNCH_OK("vamd_gn_finalize");
+    return 0;
+}
+
+int vamd_scale_shift_act(const void* x, const float* scale, const float* shift, const void* mask,
+                         float slope, void* y, int G, int64_t R, int C, int dtype, void* stream) {
+    VAMD_REQUIRE(x && scale && shift && y && G > 0 && R > 0 && C > 0, "vamd_scale_shift_act: bad argument");
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)mask % 16 == 0,
+                 "vamd_scale_shift_act: tensors must be 16-byte aligned");
+    const int64_t n = (int64_t)G * R * C;
+    VAMD_DISPATCH(dtype, "vamd_scale_shift_act", {
+        constexpr int VEC = Vec16<T>::N;
+        if (C % VEC == 0) {
+            hipLaunchKernelGGL((scale_shift_act_kernel<T, VEC>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
+                               as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope,
+                               (T*)y, R * C, C, n / VEC);
+        } else {
+            hipLaunchKernelGGL((scale_shift_act_kernel<T, 1>), dim3(grid_for(n, 256)), dim3(256), 0,
+                               as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope,
+                               (T*)y, R * C, C, n);
+        }
+    });
+    VAMD_LAUNCH_OK("vamd_scale_shift_act");
+    return 0;
+}
+
+int vamd_bn_bwd_finalize(const float* partial, int nchunk, int C, int64_t count, const float* scale,
+                         float* dgamma, float* dbeta, float* cA, float* cB, float* cC, void* stream) {
+    VAMD_REQUIRE(partial && scale && dgamma && dbeta && cA && cB && cC && nchunk > 0 && C > 0 && count > 0,
+                 "vamd_bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream),
+                       partial, nchunk, C, (double)count, scale, dgamma, dbeta, cA, cB, cC);
+    VAMD_LAUNCH_OK("vamd_bn_bwd_finalize");
+    return 0;
+}
+
+int vamd_gn_bwd_finalize(const float* partial, int nchunk, int B, int C, int groups, int64_t HW,
+                         const float* gamma, const float* rstd, float* dgamma, float* dbeta,
+                         float* cA, float* cB, float* cC, void* stream) {
+    VAMD_REQUIRE(partial && gamma && rstd && dgamma && dbeta && cA && cB && cC, "vamd_gn_bwd_finalize: null pointer");
+    VAMD_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && HW > 0 && nchunk > 0,
+                 "vamd_gn_bwd_finalize: bad shape");
+    const int total = B * groups;
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((total + 63) / 64), dim3(64), 0, as_stream(stream),
+                       partial, nchunk, B, C, groups, (double)HW * (C / groups), gamma, rstd, cA, cB, cC);
+    hipLaunchKernelGGL(sum_over_g_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), partial,
+                       nchunk, B, C, (float*)nullptr, dbeta, dgamma);
+    VAMD_LAUNCH_OK("vamd_gn_bwd_finalize");
+    return 0;
+}
+
+int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const float* scale,
+                        const float* shift, const float* mean, const float* rstd, float slope,
+                        const float* cA, const float* cB, const float* cC, const void* add,
+                        const void* add2, void* dx, int G, int64_t R, int C, int dtype,
+                        void* stream) {
+    VAMD_REQUIRE(dy && x && scale && shift && mean && rstd && cA && cB && cC && dx,
+                 "vamd_norm_bwd_apply: null pointer");
+    VAMD_REQUIRE(G > 0 && R > 0 && C > 0, "vamd_norm_bwd_apply: bad shape");
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 &&
+                     (uintptr_t)mask % 16 == 0 && (uintptr_t)add % 16 == 0 && (uintptr_t)add2 % 16 == 0,
+                 "vamd_norm_bwd_apply: tensors must be 16-byte aligned");
+    NormApplyArgs a{dy, x, mask, scale, shift, mean, rstd, cA, cB, cC, add, add2, slope};
+    const int64_t n = (int64_t)G * R * C;
+    VAMD_DISPATCH(dtype, "vamd_norm_bwd_apply", {
+        constexpr int VEC = Vec16<T>::N;
+        if (C % VEC == 0) {
+            hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
+                               as_stream(stream), a, (T*)dx, R * C, C, n / VEC);
+        } else {
+            hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(grid_for(n, 256)), dim3(256), 0,
+                               as_stream(stream), a, (T*)dx, R * C, C, n);
+        }
+    });
+    VAMD_LAUNCH_OK("vamd_norm_bwd_apply");
+    return 0;
+}
+
+int vamd_sum_finalize(const float* partial, int nchunk, int G, int C, float* per_g, float* total,
+                      void* stream) {
+    VAMD_REQUIRE(partial && nchunk > 0 && G > 0 && C > 0 && (per_g || total), "vamd_sum_finalize: bad argument");
+    hipLaunchKernelGGL(sum_over_g_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), partial,
+                       nchunk, G, C, per_g, total, (float*)nullptr);
+    VAMD_LAUNCH_OK("vamd_sum_finalize");
+    return 0;
+}
+
+}  // extern "C"

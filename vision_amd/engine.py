@@ -1,0 +1,518 @@
+"""Execution engine: runs the DDPM UNet forward and its hand-derived backward as a fixed sequence
+of libvision_amd.so kernel launches on the current HIP stream.
+
+There is no tracing and no per-op autograd: `forward` records, per layer, exactly the tensors its
+backward needs, and `backward` walks the layers in reverse, fusing every gradient merge (residual
+shortcuts, UNet skip connections) into the kernel that produces the gradient.  torch is used for
+device memory (torch.empty on the caching allocator), streams and parameters only.
+
+Layouts: activations NHWC in the compute dtype (bf16 or fp32); parameters stay fp32 in torch's
+[Cout][Cin][kh][kw] layout inside one flat arena (so state_dict()/safetensors interchange with
+the reference), with packed compute-dtype copies refreshed after every optimiser step.
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call, lib
+from .plan import LayerSpec, UNetPlan
+
+LEAKY_SLOPE = 0.01          # nn.LeakyReLU() default (reference models/ddpm.py:144)
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+GN_EPS, GN_GROUPS = 1e-6, 32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Conv:
+    """One nn.Conv2d of the reference: fp32 master weight/bias views, packed copies, launches."""
+
+    def __init__(self, eng: "Engine", name: str, cin: int, cout: int, k: int, stride=1, up=False):
+        self.eng, self.name = eng, name
+        self.cin, self.cout, self.k, self.stride, self.up = cin, cout, k, stride, up
+        self.pad = 1 if k == 3 else 0
+        self.w, self.b = eng.param(name + ".weight"), eng.param(name + ".bias")
+        self.gw, self.gb = eng.grad(name + ".weight"), eng.grad(name + ".bias")
+        self.wf = torch.empty((cout, k, k, cin), dtype=eng.dtype, device=eng.device)
+        self.wd = torch.empty((cin, k, k, cout), dtype=eng.dtype, device=eng.device)
+        self._descs: Dict[tuple, ConvDesc] = {}
+
+    def repack(self):
+        call("vamd_repack_weight", _ptr(self.w), _ptr(self.wf), _ptr(self.wd), self.cout, self.cin,
+             self.k, self.eng.dt, _stream())
+
+    def desc(self, B, H, W) -> ConvDesc:
+        key = (B, H, W)
+        d = self._descs.get(key)
+        if d is None:
+            d = ConvDesc(B, H, W, self.cin, self.cout, self.k, self.stride, self.pad, int(self.up),
+                         self.eng.dt, self.eng.algo)
+            self._descs[key] = d
+        return d
+
+    def out_hw(self, H, W):
+        if self.up:
+            return 2 * H, 2 * W
+        if self.stride == 2:
+            return (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        return H, W
+
+    def fwd(self, x, temb=None, res=None, res2=None, bias=True):
+        B, H, W, _ = x.shape
+        Ho, Wo = self.out_hw(H, W)
+        y = torch.empty((B, Ho, Wo, self.cout), dtype=self.eng.dtype, device=x.device)
+        call("vamd_conv2d_fwd", C.byref(self.desc(B, H, W)), _ptr(x), _ptr(self.wf),
+             _ptr(self.b) if bias else None, _ptr(temb), _ptr(res), _ptr(res2), _ptr(y), _stream())
+        return y
+
+    def dgrad(self, dy, in_shape, add=None):
+        B, H, W, _ = in_shape
+        d = self.desc(B, H, W)
+        dx = torch.empty(in_shape, dtype=self.eng.dtype, device=dy.device)
+        nbytes = lib.vamd_conv2d_dgrad_workspace(C.byref(d))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device) if nbytes else None
+        call("vamd_conv2d_dgrad", C.byref(d), _ptr(dy), _ptr(self.wd), _ptr(add), _ptr(dx), _ptr(ws),
+             nbytes, _stream())
+        return dx
+
+    def wgrad(self, dy, x):
+        B, H, W, _ = x.shape
+        if self.k == 1:
+            call("vamd_conv2d_wgrad", C.byref(self.desc(B, H, W)), _ptr(dy), _ptr(x), _ptr(self.gw), _stream())
+        else:
+            tmp = torch.empty(self.gw.numel(), dtype=torch.float32, device=x.device)
+            call("vamd_conv2d_wgrad", C.byref(self.desc(B, H, W)), _ptr(dy), _ptr(x), _ptr(tmp), _stream())
+            call("vamd_unpack_wgrad", _ptr(tmp), _ptr(self.gw), self.cout, self.cin, self.k, _stream())
+
+
+class _Linear:
+    """A 1x1 conv applied to a [B, C, 1, 1] map (the time-embedding path), kept in fp32."""
+
+    def __init__(self, eng, name, cin, cout, act_in):
+        self.eng, self.cin, self.cout, self.act_in = eng, cin, cout, int(act_in)
+        self.w, self.b = eng.param(name + ".weight"), eng.param(name + ".bias")
+        self.gw, self.gb = eng.grad(name + ".weight"), eng.grad(name + ".bias")
+
+    def fwd(self, x):
+        y = torch.empty((x.shape[0], self.cout), dtype=torch.float32, device=x.device)
+        call("vamd_linear_fwd", _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(y), x.shape[0], self.cin,
+             self.cout, self.act_in, LEAKY_SLOPE, _stream())
+        return y
+
+    def bwd(self, x, dy, dx=None, accumulate=False, dbias=True):
+        call("vamd_linear_bwd", _ptr(x), _ptr(self.w), _ptr(dy), _ptr(dx), _ptr(self.gw),
+             _ptr(self.gb) if dbias else None, x.shape[0], self.cin, self.cout, self.act_in, LEAKY_SLOPE,
+             int(accumulate), _stream())
+
+
+class _Norm:
+    """Statistics + fused scale/shift/LeakyReLU(/dropout) of BatchNorm2d (G = 1) or GroupNorm (G = B)."""
+
+    def __init__(self, eng, name, C_, batchnorm: bool):
+        self.eng, self.C, self.bn = eng, C_, batchnorm
+        self.gamma, self.beta = eng.param(name + ".weight"), eng.param(name + ".bias")
+        self.ggamma, self.gbeta = eng.grad(name + ".weight"), eng.grad(name + ".bias")
+        if batchnorm:
+            self.rm, self.rv = eng.buffer(name + ".running_mean"), eng.buffer(name + ".running_var")
+            self.nbt = eng.buffer(name + ".num_batches_tracked")
+        self.slope = LEAKY_SLOPE if batchnorm else 1.0
+
+    def fwd(self, x, training, mask=None):
+        B, H, W, Cc = x.shape
+        e, dev = self.eng, x.device
+        G, R = (1, B * H * W) if self.bn else (B, H * W)
+        coef = torch.empty((4, G, Cc), dtype=torch.float32, device=dev)   # scale, shift, mean, rstd
+        sc, sh, mu, rs = coef[0], coef[1], coef[2], coef[3]
+        if self.bn and not training:
+            call("vamd_bn_finalize", None, 0, Cc, 0, _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm),
+                 _ptr(self.rv), None, BN_MOMENTUM, BN_EPS, 0, _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs), _stream())
+        else:
+            nchunk = lib.vamd_stats_chunks(R)
+            part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=dev)
+            call("vamd_chan_stats", _ptr(x), _ptr(part), G, R, Cc, e.dt, _stream())
+            if self.bn:
+                call("vamd_bn_finalize", _ptr(part), nchunk, Cc, R, _ptr(self.gamma), _ptr(self.beta),
+                     _ptr(self.rm), _ptr(self.rv), _ptr(self.nbt), BN_MOMENTUM, BN_EPS, 1, _ptr(sc),
+                     _ptr(sh), _ptr(mu), _ptr(rs), _stream())
+            else:
+                call("vamd_gn_finalize", _ptr(part), nchunk, B, Cc, GN_GROUPS, H * W, _ptr(self.gamma),
+                     _ptr(self.beta), GN_EPS, _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs), _stream())
+        y = torch.empty_like(x)
+        call("vamd_scale_shift_act", _ptr(x), _ptr(sc), _ptr(sh), _ptr(mask), self.slope, _ptr(y), G, R,
+             Cc, e.dt, _stream())
+        return y, coef
+
+    def bwd(self, dy, x, coef, mask=None, add=None, add2=None, need_dx=True):
+        B, H, W, Cc = x.shape
+        e, dev = self.eng, x.device
+        G, R = (1, B * H * W) if self.bn else (B, H * W)
+        sc, sh, mu, rs = coef[0], coef[1], coef[2], coef[3]
+        nchunk = lib.vamd_stats_chunks(R)
+        part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=dev)
+        call("vamd_norm_bwd_stats", _ptr(dy), _ptr(x), _ptr(mask), _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs),
+             self.slope, _ptr(part), G, R, Cc, e.dt, _stream())
+        abc = torch.empty((3, G, Cc), dtype=torch.float32, device=dev)
+        if self.bn:
+            call("vamd_bn_bwd_finalize", _ptr(part), nchunk, Cc, R, _ptr(sc), _ptr(self.ggamma),
+                 _ptr(self.gbeta), _ptr(abc[0]), _ptr(abc[1]), _ptr(abc[2]), _stream())
+        else:
+            call("vamd_gn_bwd_finalize", _ptr(part), nchunk, B, Cc, GN_GROUPS, H * W, _ptr(self.gamma),
+                 _ptr(rs), _ptr(self.ggamma), _ptr(self.gbeta), _ptr(abc[0]), _ptr(abc[1]), _ptr(abc[2]),
+                 _stream())
+        if not need_dx:
+            return None
+        dx = torch.empty_like(x)
+        call("vamd_norm_bwd_apply", _ptr(dy), _ptr(x), _ptr(mask), _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs),
+             self.slope, _ptr(abc[0]), _ptr(abc[1]), _ptr(abc[2]), _ptr(add), _ptr(add2), _ptr(dx), G, R,
+             Cc, e.dt, _stream())
+        return dx
+
+
+def _chan_sums(eng, t, per_image: bool):
+    """Per-channel sums of an NHWC tensor: returns (per_image [B][C] or None, total [C])."""
+    B, H, W, Cc = t.shape
+    G, R = (B, H * W) if per_image else (1, B * H * W)
+    nchunk = lib.vamd_stats_chunks(R)
+    part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=t.device)
+    call("vamd_chan_stats", _ptr(t), _ptr(part), G, R, Cc, eng.dt, _stream())
+    return part, nchunk, G
+
+
+class _ResBlock:
+    """reference models/ddpm.py:43-87."""
+
+    def __init__(self, eng, spec: LayerSpec, tf: int):
+        p = spec.prefix
+        self.eng, self.spec = eng, spec
+        self.bn1 = _Norm(eng, p + ".block1.0.0", spec.cin, True)
+        self.conv1 = _Conv(eng, p + ".block1.0.2", spec.cin, spec.cout, 3)
+        self.temb = _Linear(eng, p + ".linear_temb", tf, spec.cout, act_in=True)
+        self.bn2 = _Norm(eng, p + ".block2.0.0", spec.cout, True)
+        self.conv2 = _Conv(eng, p + ".block2.0.3", spec.cout, spec.cout, 3)
+        self.short = _Conv(eng, p + ".layers.0", spec.cin, spec.cout, 1) if spec.cin != spec.cout else None
+        self.convs = [c for c in (self.conv1, self.conv2, self.short) if c is not None]
+
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None):
+        a1, coef1 = self.bn1.fwd(x, training)
+        tproj = self.temb.fwd(temb)
+        h1 = self.conv1.fwd(a1, temb=tproj)
+        mask = None
+        if training and self.spec.dropout > 0.0:
+            mask = drop_mask if drop_mask is not None else self.eng.draw_dropout(h1.shape, self.spec.dropout)
+        a2, coef2 = self.bn2.fwd(h1, training, mask)
+        sc = self.short.fwd(x) if self.short is not None else x
+        y = self.conv2.fwd(a2, res=sc, res2=res2)
+        if tape is not None:
+            tape.append((self, (x, a1, coef1, h1, a2, coef2, mask, temb)))
+        return y
+
+    def bwd(self, saved, dy, extra, dtemb, need_dx=True):
+        x, a1, coef1, h1, a2, coef2, mask, temb = saved
+        e = self.eng
+        # conv2 and shortcut share dy; their bias gradients are the same column sums of dy
+        part, nchunk, G = _chan_sums(e, dy, False)
+        call("vamd_sum_finalize", _ptr(part), nchunk, G, self.spec.cout, None, _ptr(self.conv2.gb), _stream())
+        self.conv2.wgrad(dy, a2)
+        da2 = self.conv2.dgrad(dy, a2.shape)
+        dxs = dy
+        if self.short is not None:
+            self.short.gb.copy_(self.conv2.gb)
+            self.short.wgrad(dy, x)
+            dxs = self.short.dgrad(dy, x.shape) if need_dx else None
+        dh1 = self.bn2.bwd(da2, h1, coef2, mask)
+        # d(projected temb)[b][c] = sum over pixels of dh1; conv1 bias gradient = its sum over b
+        part, nchunk, G = _chan_sums(e, dh1, True)
+        dtproj = torch.empty((G, self.spec.cout), dtype=torch.float32, device=dy.device)
+        call("vamd_sum_finalize", _ptr(part), nchunk, G, self.spec.cout, _ptr(dtproj), _ptr(self.conv1.gb), _stream())
+        self.temb.bwd(temb, dtproj, dx=dtemb, accumulate=True)
+        self.conv1.wgrad(dh1, a1)
+        da1 = self.conv1.dgrad(dh1, a1.shape)
+        return self.bn1.bwd(da1, x, coef1, None, add=dxs, add2=extra, need_dx=need_dx)
+
+
+class _AttnBlock:
+    """reference models/ddpm.py:89-123: GroupNorm, q/k/v 1x1 convs, single-head softmax attention
+    over the H*W positions, output 1x1 conv, residual."""
+
+    def __init__(self, eng, spec: LayerSpec):
+        p = spec.prefix
+        self.eng, self.spec, self.C = eng, spec, spec.cout
+        self.norm = _Norm(eng, p + ".norm", self.C, False)
+        self.q = _Conv(eng, p + ".q_proj", self.C, self.C, 1)
+        self.k = _Conv(eng, p + ".k_proj", self.C, self.C, 1)
+        self.v = _Conv(eng, p + ".v_proj", self.C, self.C, 1)
+        self.o = _Conv(eng, p + ".linear", self.C, self.C, 1)
+        self.convs = [self.q, self.k, self.v, self.o]
+
+    # Rows of the [S x S] score / probability matrices are padded to Sp = S rounded up to 8
+    # elements (16 bytes of bf16) with zeros, so every row is a whole number of 16-byte pieces.
+    def _bmm_nt(self, A, Bm, out, batch, M, N, K, lda, ldb, ldc, alpha):
+        e = self.eng
+        call("vamd_bmm_nt", _ptr(A), _ptr(Bm), _ptr(out), batch, M, N, K, lda, ldb, ldc, alpha, e.dt,
+             int(out.dtype == torch.float32), e.algo, _stream())
+        return out
+
+    def _bmm_tn(self, A, Bm, out, batch, M, N, K, lda, ldb, ldc):
+        e = self.eng
+        call("vamd_bmm_tn", _ptr(A), _ptr(Bm), _ptr(out), batch, M, N, K, lda, ldb, ldc, 1.0, e.dt, e.algo, _stream())
+        return out
+
+    def _transpose_padded(self, t, batch, R, Cc, ld):
+        out = torch.zeros((batch, Cc, ld), dtype=t.dtype, device=t.device)
+        call("vamd_transpose", _ptr(t), _ptr(out), batch, R, Cc, ld, self.eng.dt, _stream())
+        return out
+
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None):
+        B, H, W, Cc = x.shape
+        S = H * W
+        Sp = (S + 7) // 8 * 8
+        e, dev = self.eng, x.device
+        hn, coef = self.norm.fwd(x, training)
+        q, k, v = self.q.fwd(hn), self.k.fwd(hn), self.v.fwd(hn)
+        scores = torch.empty((B, S, Sp), dtype=torch.float32, device=dev)     # [B][query][key]
+        self._bmm_nt(q, k, scores, B, S, S, Cc, Cc, Cc, Sp, Cc ** -0.5)
+        P = torch.zeros((B, S, Sp), dtype=e.dtype, device=dev)
+        call("vamd_softmax_rows", _ptr(scores), _ptr(P), B * S, S, Sp, e.dt, _stream())
+        vT = self._transpose_padded(v, B, S, Cc, Sp)                          # [B][C][Sp]
+        o = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)             # o[s][c] = sum_t P[s][t] v[t][c]
+        self._bmm_nt(P, vT, o, B, S, Cc, S, Sp, Sp, Cc, 1.0)
+        y = self.o.fwd(o, res=x, res2=res2)
+        if tape is not None:
+            tape.append((self, (x, hn, coef, q, k, v, P, o)))
+        return y
+
+    def bwd(self, saved, dy, extra, dtemb, need_dx=True):
+        x, hn, coef, q, k, v, P, o = saved
+        e, dev = self.eng, x.device
+        B, H, W, Cc = x.shape
+        S = H * W
+        Sp = P.shape[2]
+        part, nchunk, G = _chan_sums(e, dy, False)
+        call("vamd_sum_finalize", _ptr(part), nchunk, G, Cc, None, _ptr(self.o.gb), _stream())
+        self.o.wgrad(dy, o)
+        do = self.o.dgrad(dy, o.shape)
+        dP = torch.empty((B, S, Sp), dtype=torch.float32, device=dev)         # dP[s][t] = sum_c do[s][c] v[t][c]
+        self._bmm_nt(do, v, dP, B, S, S, Cc, Cc, Cc, Sp, 1.0)
+        dv = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)            # dv[t][c] = sum_s P[s][t] do[s][c]
+        self._bmm_tn(P, do, dv, B, S, Cc, S, Sp, Cc, Cc)
+        dS = torch.zeros((B, S, Sp), dtype=e.dtype, device=dev)
+        call("vamd_softmax_rows_bwd", _ptr(P), _ptr(dP), _ptr(dS), B * S, S, Sp, Cc ** -0.5, e.dt, _stream())
+        kT = self._transpose_padded(k, B, S, Cc, Sp)
+        dq = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)            # dq[s][c] = sum_t dS[s][t] k[t][c]
+        self._bmm_nt(dS, kT, dq, B, S, Cc, S, Sp, Sp, Cc, 1.0)
+        dk = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)            # dk[t][c] = sum_s dS[s][t] q[s][c]
+        self._bmm_tn(dS, q, dk, B, S, Cc, S, Sp, Cc, Cc)
+        dhn = None
+        for conv, g in ((self.q, dq), (self.k, dk), (self.v, dv)):
+            part, nchunk, G = _chan_sums(e, g, False)
+            call("vamd_sum_finalize", _ptr(part), nchunk, G, Cc, None, _ptr(conv.gb), _stream())
+            conv.wgrad(g, hn)
+            dhn = conv.dgrad(g, hn.shape, add=dhn)
+        return self.norm.bwd(dhn, x, coef, None, add=dy, add2=extra, need_dx=need_dx)
+
+
+class _Resample:
+    """DownBlock (conv 3x3 stride 2) / UpBlock (nearest 2x upsample fused into a conv 3x3);
+    reference models/ddpm.py:14-41."""
+
+    def __init__(self, eng, spec: LayerSpec):
+        p = spec.prefix
+        self.eng, self.spec = eng, spec
+        if spec.kind == "down":
+            self.conv = _Conv(eng, p + ".layers.0", spec.cin, spec.cout, 3, stride=2)
+        else:
+            self.conv = _Conv(eng, p + ".layers.1", spec.cin, spec.cout, 3, up=True)
+        self.convs = [self.conv]
+
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None):
+        y = self.conv.fwd(x, res2=res2)
+        if tape is not None:
+            tape.append((self, (x,)))
+        return y
+
+    def bwd(self, saved, dy, extra, dtemb, need_dx=True):
+        (x,) = saved
+        part, nchunk, G = _chan_sums(self.eng, dy, False)
+        call("vamd_sum_finalize", _ptr(part), nchunk, G, self.spec.cout, None, _ptr(self.conv.gb), _stream())
+        self.conv.wgrad(dy, x)
+        return self.conv.dgrad(dy, x.shape, add=extra)
+
+
+class Engine:
+    def __init__(self, module: torch.nn.Module, plan: UNetPlan, dtype: torch.dtype, algo=_lib.ALGO_AUTO):
+        params = list(module.named_parameters())
+        if not params or params[0][1].device.type != "cuda":
+            raise RuntimeError("vision_amd needs its parameters on a HIP device (cuda:N); there is no CPU path")
+        if not plan.with_conv:
+            raise NotImplementedError("with_conv=False (AvgPool2d / bare Upsample resampling) has no HIP kernels yet")
+        self.device = params[0][1].device
+        self.plan, self.dtype, self.algo = plan, dtype, algo
+        self.dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}[dtype]
+
+        # one flat fp32 arena for parameters and one for gradients; every nn.Parameter becomes a view
+        sizes = [p.numel() for _, p in params]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 3) // 4 * 4              # keep every tensor 16-byte aligned
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._p, self._g = {}, {}
+        self.param_slices = {}
+        with torch.no_grad():
+            for (name, p), off, n in zip(params, offs, sizes):
+                view = self.flat_p[off:off + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                g = self.flat_g[off:off + n].view(p.shape)
+                p.grad = g
+                self._p[name], self._g[name] = view, g
+                self.param_slices[name] = (off, n)
+        self._b = dict(module.named_buffers())
+        self._params = [p for _, p in params]
+        self._versions = None
+
+        tf = plan.time_features
+        self.lin1 = _Linear(self, "linear_1", plan.ch, tf, act_in=False)
+        self.lin2 = _Linear(self, "linear_2", tf, tf, act_in=True)
+        self.layers = []
+        for spec in plan.layers:
+            if spec.kind == "res":
+                self.layers.append(_ResBlock(self, spec, tf))
+            elif spec.kind == "attn":
+                self.layers.append(_AttnBlock(self, spec))
+            else:
+                self.layers.append(_Resample(self, spec))
+        self.end = _Conv(self, "End.0.0", plan.end_channels, plan.end_channels, 1)
+        self.n_down = len(plan.section("Downsampling"))
+        self.n_mid = len(plan.section("Middle"))
+        # 2*pi*exp(linspace(ln 1, ln 1000, ch/2)) tabulated with the reference's own op sequence
+        # (models/ddpm.py:126-134) on the host, once
+        freqs = torch.exp(torch.linspace(math.log(1.0), math.log(1000.0), plan.ch // 2))
+        self.angular = (2.0 * math.pi * freqs).to(self.device)
+        self.dirty = True
+        self.drop_generator = None
+        self.debug_taps = None            # dict -> receives (output, folded skip) per layer (diagnostics)
+
+    # ---- parameter access for the layer objects
+    def param(self, name):
+        return self._p[name]
+
+    def grad(self, name):
+        return self._g[name]
+
+    def buffer(self, name):
+        return self._b[name]
+
+    def owns(self, module) -> bool:
+        p = next(module.parameters())
+        if p.data_ptr() != self.flat_p.data_ptr():
+            return False
+        if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr():
+            self.attach_grads()
+        return True
+
+    def all_convs(self):
+        for layer in self.layers:
+            yield from layer.convs
+        yield self.end
+
+    def refresh(self):
+        """Re-pack the compute-dtype weight copies if any master weight changed."""
+        vers = [p._version for p in self._params]
+        if self.dirty or vers != self._versions:
+            for c in self.all_convs():
+                c.repack()
+            self._versions = vers
+            self.dirty = False
+
+    def draw_dropout(self, shape, p):
+        keep = torch.full(shape, 1.0 - p, dtype=torch.float32, device=self.device)
+        return (torch.bernoulli(keep, generator=self.drop_generator) / (1.0 - p)).to(self.dtype)
+
+    # ---- UNet forward / backward on NHWC tensors
+    def forward(self, x, t, training: bool, tape: Optional[list], drop_masks=None):
+        """x: [B,H,W,3] compute dtype; t: [B] fp32 (the reference feeds noise_rate**2).
+        Returns the NHWC prediction; if `tape` is a list it receives what backward needs."""
+        self.refresh()
+        B = x.shape[0]
+        drop_masks = drop_masks or {}
+        emb = torch.empty((B, self.plan.ch), dtype=torch.float32, device=x.device)
+        call("vamd_timeembed", _ptr(t), _ptr(self.angular), _ptr(emb), B, self.plan.ch, _stream())
+        t1 = self.lin1.fwd(emb)
+        temb = self.lin2.fwd(t1)
+        if tape is not None:
+            tape.append(("temb", (emb, t1, temb)))
+        skips: List[torch.Tensor] = []
+        h = x
+        nd, nm = self.n_down, self.n_mid
+        n_up = len(self.layers) - nd - nm
+        for i, layer in enumerate(self.layers):
+            # the reference adds skip[j] (reversed order) in place to the input of up module j
+            # (models/ddpm.py:228-232); here the producer of that input adds it in its epilogue
+            res2 = None
+            j = i + 1 - nd - nm                     # index of the up module consuming this output
+            if 0 <= j < n_up and j < nd:
+                res2 = skips[nd - 1 - j]
+            h = layer.fwd(h, temb, training, res2, tape, drop_masks.get(layer.spec.prefix))
+            if self.debug_taps is not None:
+                self.debug_taps[layer.spec.prefix] = (h, res2)
+            if i < nd:
+                skips.append(h)
+        if nm == 0 and n_up > 0 and nd > 0:
+            raise RuntimeError("unexpected plan without Middle section")
+        out = self.end.fwd(h)
+        if tape is not None:
+            tape.append(("end", (h,)))
+        return out
+
+    def backward(self, tape: list, dout):
+        """dout: gradient of the NHWC prediction.  Writes every parameter gradient into the flat
+        gradient arena (overwriting), returns nothing (the network input needs no gradient)."""
+        tag, (h_end,) = tape.pop()
+        assert tag == "end"
+        part, nchunk, G = _chan_sums(self, dout, False)
+        call("vamd_sum_finalize", _ptr(part), nchunk, G, self.end.cout, None, _ptr(self.end.gb), _stream())
+        self.end.wgrad(dout, h_end)
+        g = self.end.dgrad(dout, h_end.shape)
+        nd, nm = self.n_down, self.n_mid
+        n_up = len(self.layers) - nd - nm
+        B = dout.shape[0]
+        dtemb = torch.zeros((B, self.plan.time_features), dtype=torch.float32, device=dout.device)
+        dskip: Dict[int, torch.Tensor] = {}
+        for i in range(len(self.layers) - 1, -1, -1):
+            layer, saved = tape.pop()
+            assert layer is self.layers[i]
+            j = i - nd - nm                         # up-module index (>= 0 inside Upsampling)
+            # gradient reaching the output of layer i-1 = dx of layer i (+ the skip gradient if
+            # layer i-1 is a down module whose output was also used as a skip)
+            extra = dskip.pop(i - 1, None) if i - 1 < nd else None
+            g_in = layer.bwd(saved, g, extra, dtemb, need_dx=(i > 0))
+            if 0 <= j < nd:
+                # input of up module j was h + skip[nd-1-j]: the same gradient also reaches that skip.
+                # `extra` was already folded into g_in for layer i-1, so hand the skip the plain part:
+                # for up modules i-1 >= nd, hence extra is None and g_in is exactly that gradient.
+                dskip[nd - 1 - j] = g_in
+            g = g_in
+        tag, (emb, t1, temb) = tape.pop()
+        assert tag == "temb"
+        dt1 = torch.empty_like(t1)
+        self.lin2.bwd(t1, dtemb, dx=dt1)
+        self.lin1.bwd(emb, dt1, dx=None)
+        self.attach_grads()
+
+    def attach_grads(self):
+        """Make sure every parameter's .grad is its view of the gradient arena (an optimiser's
+        zero_grad(set_to_none=True) detaches them)."""
+        for (name, g), p in zip(self._g.items(), self._params):
+            if p.grad is not g:
+                p.grad = g

@@ -1,0 +1,92 @@
+"""Static layer plan of the DDPM UNet, derived from the reference's YAML `model_config`.
+
+The reference builds its module lists imperatively in `DDPMModel.__init__`
+(reference models/ddpm.py:160-204); here the same decisions produce a flat list of `LayerSpec`
+records that both the parameter containers (ddpm.py) and the HIP execution engine (engine.py)
+are generated from, so that they cannot disagree.
+"""
+from dataclasses import dataclass
+from typing import List
+
+REQUIRED_KEYS = ("h_dims", "patch_size", "attn_res", "down_index", "with_conv", "dropout",
+                 "latent_dim", "sampling_period", "diffusion_steps", "grid")
+
+
+@dataclass(frozen=True)
+class LayerSpec:
+    section: str      # 'Downsampling' | 'Middle' | 'Upsampling'
+    index: int        # position inside the section's ModuleList
+    kind: str         # 'res' | 'attn' | 'down' | 'up'
+    cin: int
+    cout: int
+    res_in: int       # spatial extent of the module's input
+    res_out: int
+    dropout: float = 0.0
+
+    @property
+    def prefix(self):
+        return f"{self.section}.{self.index}"
+
+
+@dataclass(frozen=True)
+class UNetPlan:
+    layers: List[LayerSpec]
+    ch: int               # width of the sinusoidal embedding (h_dims[1])
+    time_features: int    # 4 * ch
+    end_channels: int
+    patch_size: int
+    with_conv: bool
+
+    def section(self, name):
+        return [l for l in self.layers if l.section == name]
+
+
+def make_plan(config) -> UNetPlan:
+    for k in REQUIRED_KEYS:
+        if k not in config:
+            raise KeyError(k)          # the reference indexes config[...] directly (models/ddpm.py:142-153)
+    dims = list(config["h_dims"])
+    down_flags = list(config["down_index"])
+    attn_at = list(config["attn_res"])
+    levels = len(dims) - 1
+    layers: List[LayerSpec] = []
+
+    # The reference tracks the feature resolution in a variable that becomes a float after the
+    # first halving and tests `f_res in attn_res`; int/float equality makes 112.0 match 112.
+    res = config["patch_size"]
+    pos = 0
+    width = dims[0]
+    for lvl in range(levels):
+        width_in, width = dims[lvl], dims[lvl + 1]
+        layers.append(LayerSpec("Downsampling", pos, "res", width_in, width, int(res), int(res)))
+        pos += 1
+        if res in attn_at:                                   # checked before the level's DownBlock
+            layers.append(LayerSpec("Downsampling", pos, "attn", width, width, int(res), int(res)))
+            pos += 1
+        if down_flags[lvl + 1] == 1:
+            half = (int(res) - 1) // 2 + 1                   # conv 3x3 stride 2 pad 1 (== res/2 for even res)
+            layers.append(LayerSpec("Downsampling", pos, "down", width, width, int(res), half))
+            pos += 1
+            res = res / 2
+
+    p = float(config["dropout"])
+    r = int(res)
+    layers.append(LayerSpec("Middle", 0, "res", width, width, r, r, p))
+    layers.append(LayerSpec("Middle", 1, "attn", width, width, r, r))
+    layers.append(LayerSpec("Middle", 2, "res", width, width, r, r, p))
+
+    rdims, rflags = dims[::-1], down_flags[::-1]
+    pos = 0
+    for lvl in range(levels):
+        width_in, width = rdims[lvl], rdims[lvl + 1]
+        if rflags[lvl] == 1:
+            layers.append(LayerSpec("Upsampling", pos, "up", width_in, width_in, int(res), int(res) * 2))
+            pos += 1
+            res = res * 2
+        layers.append(LayerSpec("Upsampling", pos, "res", width_in, width, int(res), int(res)))
+        pos += 1
+        if res in attn_at:                                   # checked after the level's UpBlock
+            layers.append(LayerSpec("Upsampling", pos, "attn", width, width, int(res), int(res)))
+            pos += 1
+    return UNetPlan(layers=layers, ch=dims[1], time_features=4 * dims[1], end_channels=width,
+                    patch_size=int(config["patch_size"]), with_conv=bool(config["with_conv"]))
