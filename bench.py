@@ -1,0 +1,207 @@
+"""Benchmark of the DDPM UNet training step (and sampler) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--preset butterfly] [--batch B]
+
+One "step" = one full training step of the hot path on one synthetic ImageFolder-shaped batch per
+GPU: schedule + q_sample, UNet forward, L1 loss, hand-written backward, (bucketed RCCL gradient
+all-reduce when N > 1), fused AdamW, weight re-pack.  Inputs are resident in HBM before the timed
+region.  The workload at N = 1 is BASELINE.json configs[1]: configs/butterfly_ddpm.yaml,
+batch 64 per GPU, 224x224, bf16 compute.  N > 1 is weak scaling (64 images per GPU).
+
+Rank 0 prints ONE JSON line: metric value = training images/s over all GPUs, plus
+  roofline     - the MFMA implicit-GEMM kernel (forward + input-gradient launches): algorithmic
+                 FLOPs / device time measured with HIP events around every launch;
+  cpu_baseline - the oracle's CPU restatement timed on a bounded sample of configs[0]
+                 (flowers model, batch 8), N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preset", default="butterfly")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the preset's data_config.batch_size)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampling", action="store_true")
+    ap.add_argument("--sample-steps", type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Oracle (plain-PyTorch CPU restatement of the reference) on BASELINE configs[0]: flowers model,
+    batch 8, fp32: training steps until the budget is used, then one 2-step sampling of 4 images."""
+    from oracle import restatement as R
+    from vision_amd.presets import get_preset
+    cfg = get_preset("flowers")["model_config"]
+    sd = R.init_state_like_torch(cfg, cfg["manual_seed"])
+    names = [k for k in sd if R.is_param(k)]
+    m = {k: torch.zeros_like(sd[k]) for k in names}
+    v = {k: torch.zeros_like(sd[k]) for k in names}
+    g = torch.Generator().manual_seed(0)
+    B, P = 8, cfg["patch_size"]
+    x = torch.rand((B, 3, P, P), generator=g)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        eps = torch.randn((B, 3, P, P), generator=g)
+        t = torch.rand((B, 1, 1, 1), generator=g)
+        loss, grads = R.loss_and_grads(sd, cfg, x, eps, t)
+        R.adamw_step({k: sd[k] for k in names}, grads, m, v, steps + 1, cfg["learning_rate"], cfg["weight_decay"])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget * 0.7 or steps >= 20:
+            break
+    train_ips = steps * B / el
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        R.reverse_diffusion(sd, cfg, torch.randn((4, 3, P, P), generator=g), 2)
+    samp = time.perf_counter() - t1
+    return {"value": round(train_ips, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"flowers_ddpm model, batch 8, fp32, {steps} training steps ({el:.1f} s) on the host CPU; "
+                      f"sampling 4 images x 2 steps took {samp:.1f} s = {4 * 2 / samp:.2f} image-steps/s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl")
+    rank = dist.get_rank() if world > 1 else 0
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    import vision_amd
+    from vision_amd.parallel import DataParallel
+    from vision_amd.presets import get_preset
+
+    preset = get_preset(args.preset)
+    cfg = preset["model_config"]
+    B = args.batch or preset["data_config"]["batch_size"]
+    P = cfg["patch_size"]
+    torch.manual_seed(cfg["manual_seed"])
+    model = vision_amd.get_model("ddpm", cfg, compute_dtype=args.dtype).to(dev).train()
+    dp = DataParallel(model)
+    eng = model._ensure_engine()
+    opt = model.configure_optimizers()[0][0]
+
+    gen = torch.Generator(device="cpu").manual_seed(rank)
+    nbatch = 2
+    batches = [(torch.rand((B, 3, P, P), generator=gen).to(dev), torch.zeros(B, dtype=torch.int64, device=dev))
+               for _ in range(nbatch)]
+
+    def step(i):
+        dp.broadcast_buffers()
+        loss = model.training_step(batches[i % nbatch], i)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    model.train_losses.clear()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    eng.profile = []          # (kind, flops, start_event, end_event) per MFMA conv launch
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof, eng.profile = eng.profile, None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ips = world * B * args.steps / elapsed
+    final_loss = float(loss)
+
+    # roofline of the dominant kernel: MFMA implicit-GEMM "NT" (forward + input gradient)
+    kinds = {}
+    for kind, flops, e0, e1 in prof:
+        ms = e0.elapsed_time(e1)
+        f, t, n = kinds.get(kind, (0.0, 0.0, 0))
+        kinds[kind] = (f + flops, t + ms, n + 1)
+    roof = None
+    if "nt" in kinds:
+        f, t, n = kinds["nt"]
+        ach = f / (t * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_nt_mfma_kernel<bf16> (implicit-GEMM forward + dgrad)",
+                "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": n, "avg_launch_ms": round(t / n, 4), "flops_per_launch": f / n}
+    extra = {}
+    if "tn" in kinds:
+        f, t, n = kinds["tn"]
+        extra["wgrad_kernel"] = {"kernel": "conv_tn_mfma_kernel<bf16> (weight gradient)", "achieved_tflops": round(f / (t * 1e-3) / 1e12, 1),
+                                 "launches": n, "avg_launch_ms": round(t / n, 4)}
+    conv_ms = sum(v[1] for v in kinds.values()) / max(args.steps, 1)
+    extra["mfma_conv_ms_per_step"] = round(conv_ms, 3)
+
+    sampling = None
+    if not args.no_sampling:
+        model.eval()
+        nimg = min(B, 16)
+        noise = torch.randn((nimg, 3, P, P), device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank))
+        model.generate(nimg, 2, initial_noise=noise)
+        fence()
+        t1 = time.perf_counter()
+        model.generate(nimg, args.sample_steps, initial_noise=noise)
+        fence()
+        ts = time.perf_counter() - t1
+        sampling = {"images_per_s": round(world * nimg / ts, 3), "diffusion_steps": args.sample_steps,
+                    "images_per_gpu": nimg, "image_steps_per_s": round(world * nimg * args.sample_steps / ts, 2)}
+
+    if rank == 0:
+        from vision_amd.flops import train_flops_per_image
+        tf = train_flops_per_image(cfg)
+        out = {
+            "metric": "DDPM UNet train images/s (butterfly_ddpm UNet, 224x224, bf16)" if args.preset == "butterfly"
+            else f"DDPM UNet train images/s ({args.preset}_ddpm)",
+            "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"configs/{args.preset}_ddpm.yaml UNet training step, per-GPU batch {B}, "
+                                   f"{P}x{P}, synthetic ImageFolder-shaped images, random-init weights (seed 42)",
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "train_tflops_per_s": round(ips * tf / 1e12, 1),
+            "train_frac_of_bf16_mfma_peak": round(ips * tf / 1e12 / (BF16_MFMA_PEAK_TFLOPS * world), 4),
+            "final_loss": round(final_loss, 5),
+            "roofline": roof, "sampling": sampling, **extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

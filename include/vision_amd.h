@@ -44,7 +44,7 @@ typedef struct vamd_conv_desc {
     int32_t pad;       /* 0 or 1 */
     int32_t upsample;  /* 1: input is read through a nearest-neighbour 2x upsample */
     int32_t dtype;     /* VAMD_F32 | VAMD_BF16 (activations and packed weights) */
-    int32_t algo;      /* 0 auto, 1 force direct kernels, 2 force MFMA kernels */
+    int32_t algo;      /* 0 auto (thin -> MFMA -> direct), 1 direct, 2 MFMA, 3 thin-channel kernels */
 } vamd_conv_desc;
 
 /* y = conv(x, w) + bias[c] + temb[b][c] + residual + residual2; each addend may be NULL.
@@ -67,9 +67,15 @@ int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, 
  * fused upsample is formed at the upsampled resolution first). */
 size_t vamd_conv2d_dgrad_workspace(const vamd_conv_desc* d);
 
-/* dw[Cout][kh][kw][Cin] (fp32) = sum over pixels of dy (x) x.  Overwrites dw. */
+/* dw[Cout][kh][kw][Cin] (fp32) = sum over pixels of dy (x) x.  Overwrites dw.  `workspace` must
+ * hold vamd_conv2d_wgrad_workspace(d) bytes (partial sums of the thin-channel kernels; 0 otherwise). */
 int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw,
-                      void* stream);
+                      void* workspace, size_t workspace_bytes, void* stream);
+size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d);
+
+/* 1 if the MFMA implicit-GEMM kernels serve this descriptor for pass 0 (forward), 1 (input
+ * gradient) or 2 (weight gradient), 0 if the direct kernels do. */
+int vamd_conv2d_uses_mfma(const vamd_conv_desc* d, int pass);
 
 /* fp32 [Cout][Cin][k][k] (torch layout) -> w_fwd [Cout][k][k][Cin] and, if non-NULL,
  * w_dgrad [Cin][k][k][Cout] flipped, both in `dtype`. */
@@ -82,9 +88,9 @@ int vamd_unpack_wgrad(const float* dw_krsc, float* dw_oihw, int Cout, int Cin, i
 /* ------------------------------------------------------- normalisation + activation
  * Per-(g, c) sum and sum of squares of x viewed as [G][R][C] (BatchNorm: G = 1, R = B*H*W;
  * GroupNorm / per-image sums: G = B, R = H*W).  `partial` holds G * nchunk * C * 2 floats,
- * nchunk = vamd_stats_chunks(R).  Deterministic (no atomics).
+ * nchunk = vamd_stats_chunks(R, G).  Deterministic (no atomics).
  * Replaces the statistics half of nn.BatchNorm2d (models/ddpm.py:50,56) / nn.GroupNorm (:93). */
-int vamd_stats_chunks(int64_t R);
+int vamd_stats_chunks(int64_t R, int G);
 int vamd_chan_stats(const void* x, float* partial, int G, int64_t R, int C, int dtype,
                     void* stream);
 /* As vamd_chan_stats, for the backward pass: sums of gz and gz*xhat where

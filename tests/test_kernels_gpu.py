@@ -86,6 +86,11 @@ CONV_CASES = [
     (2, 8, 8, 3, 3, 3, 1, 0),
     (2, 8, 8, 3, 32, 1, 1, 0),
     (2, 8, 8, 3, 3, 1, 1, 0),
+    (3, 37, 29, 3, 64, 3, 1, 0),
+    (3, 37, 29, 64, 3, 3, 1, 0),
+    (2, 20, 20, 64, 3, 1, 1, 0),
+    (2, 20, 20, 3, 64, 1, 1, 0),
+    (2, 19, 23, 3, 40, 3, 1, 0),
 ]
 
 
@@ -100,13 +105,15 @@ def mfma_ok(cin, cout, dts):
     return cin % piece == 0 and 2 * cin >= kstep and cout % piece == 0
 
 
-@pytest.mark.parametrize("algo", [_lib.ALGO_DIRECT, _lib.ALGO_MFMA])
+@pytest.mark.parametrize("algo", [_lib.ALGO_DIRECT, _lib.ALGO_MFMA, _lib.ALGO_THIN])
 @pytest.mark.parametrize("dts", ["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(case, dts, algo):
     B, H, W, Cin, Cout, k, stride, up = case
     if algo == _lib.ALGO_MFMA and not (mfma_ok(Cin, Cout, dts) and mfma_ok(Cout, Cin, dts)):
         pytest.skip("shape outside the MFMA path")
+    if algo == _lib.ALGO_THIN and not (stride == 1 and not up and min(Cin, Cout) <= 4):
+        pytest.skip("shape outside the thin-channel kernels")
     tdt, dt = DT[dts]
     gen = torch.Generator().manual_seed(hash(case) % 1000)
     x, x64 = rnd((B, Cin, H, W), tdt, gen)
@@ -145,7 +152,9 @@ def test_conv_fwd_dgrad_wgrad(case, dts, algo):
     assert relerr(dx.permute(0, 3, 1, 2), gx64 + add64) < TOL_OUT[dts]
 
     dwk = torch.full((Cout, k, k, Cin), 7.0, dtype=torch.float32, device=DEV)   # must be overwritten
-    call("vamd_conv2d_wgrad", C.byref(d), P(dyn), P(xn), P(dwk), S())
+    wbytes = lib.vamd_conv2d_wgrad_workspace(C.byref(d))
+    wws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=DEV)
+    call("vamd_conv2d_wgrad", C.byref(d), P(dyn), P(xn), P(dwk), P(wws), wbytes, S())
     dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=DEV)
     call("vamd_unpack_wgrad", P(dwk), P(dw), Cout, Cin, k, S())
     assert relerr(dw, gw64) < TOL_F32OUT[dts]
@@ -223,7 +232,7 @@ def test_batchnorm_act_fwd_bwd(shape, dts):
     y64 = F.leaky_relu(F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5), 0.01) * mask64
 
     R = B * H * W
-    nchunk = lib.vamd_stats_chunks(R)
+    nchunk = lib.vamd_stats_chunks(R, 1)
     part = torch.empty((1, nchunk, Cc, 2), dtype=torch.float32, device=DEV)
     call("vamd_chan_stats", P(x), P(part), 1, R, Cc, dt, S())
     coef = torch.empty((4, Cc), dtype=torch.float32, device=DEV)
@@ -273,7 +282,7 @@ def test_groupnorm_fwd_bwd(shape, dts):
     g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
     y64 = F.group_norm(x64, 32, g64, b64, 1e-6)
     R = H * W
-    nchunk = lib.vamd_stats_chunks(R)
+    nchunk = lib.vamd_stats_chunks(R, B)
     part = torch.empty((B, nchunk, Cc, 2), dtype=torch.float32, device=DEV)
     call("vamd_chan_stats", P(x), P(part), B, R, Cc, dt, S())
     coef = torch.empty((4, B, Cc), dtype=torch.float32, device=DEV)

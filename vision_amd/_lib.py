@@ -1,16 +1,21 @@
 """ctypes binding of libvision_amd.so (the C ABI declared in include/vision_amd.h).
 
-The library is built in-tree by `python -m vision_amd.build_ext` (hipcc, gfx950).  There is no
+The library is built in-tree by `python vision_amd/build_ext.py` (hipcc, gfx950).  There is no
 fallback: if the shared object is missing, importing this module raises.
 """
 import ctypes as C
 import os
 
+# torch must be imported first: its wheel bundles the HIP runtime (libamdhip64) that owns the
+# device memory and streams handed to this library; loading libvision_amd.so first would pull a
+# second copy of the runtime from /opt/rocm into the process.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvision_amd.so")
 
 F32, BF16 = 0, 1
-ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_THIN = 0, 1, 2, 3
 
 
 class VamdError(RuntimeError):
@@ -24,7 +29,7 @@ class ConvDesc(C.Structure):
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
-        f"{LIB_PATH} not found: build the HIP extension first (python -m vision_amd.build_ext). "
+        f"{LIB_PATH} not found: build the HIP extension first (python vision_amd/build_ext.py). "
         "vision_amd has no CPU or eager fallback.")
 
 lib = C.CDLL(LIB_PATH)
@@ -39,10 +44,12 @@ SIGNATURES = {
     "vamd_conv2d_fwd": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vamd_conv2d_dgrad": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
     "vamd_conv2d_dgrad_workspace": (_z, [_d]),
-    "vamd_conv2d_wgrad": (_i, [_d, _p, _p, _p, _p]),
+    "vamd_conv2d_wgrad": (_i, [_d, _p, _p, _p, _p, _z, _p]),
+    "vamd_conv2d_wgrad_workspace": (_z, [_d]),
+    "vamd_conv2d_uses_mfma": (_i, [_d, _i]),
     "vamd_repack_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vamd_unpack_wgrad": (_i, [_p, _p, _i, _i, _i, _p]),
-    "vamd_stats_chunks": (_i, [_l]),
+    "vamd_stats_chunks": (_i, [_l, _i]),
     "vamd_chan_stats": (_i, [_p, _p, _i, _l, _i, _i, _p]),
     "vamd_norm_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _i, _p]),
     "vamd_bn_finalize": (_i, [_p, _i, _i, _l, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),

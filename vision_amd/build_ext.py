@@ -1,4 +1,4 @@
-"""Builds libvision_amd.so (gfx950) in-tree with hipcc.  `python -m vision_amd.build_ext`."""
+"""Builds libvision_amd.so (gfx950) in-tree with hipcc.  `python vision_amd/build_ext.py` (run as a script: importing the package needs the library)."""
 import os
 import subprocess
 import sys

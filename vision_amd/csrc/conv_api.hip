@@ -35,6 +35,26 @@ int conv_geom(const vamd_conv_desc* d, ConvGeom* g, const char* who) {
 
 using namespace vamd;
 
+namespace {
+// algo: 0 auto (thin -> MFMA -> direct), 1 direct, 2 MFMA, 3 thin
+enum { kAuto = 0, kDirect = 1, kMfma = 2, kThin = 3 };
+
+ConvGeom transposed(const ConvGeom& g) {      // geometry of the stride-1 input gradient seen as a convolution
+    ConvGeom t = g;
+    t.Cin = g.Cout;
+    t.Cout = g.Cin;
+    return t;
+}
+
+int pick(int algo, bool thin_ok, bool mfma_ok, const char* who, const ConvGeom& g) {
+    if (algo == kDirect) return kDirect;
+    if (algo == kThin) return thin_ok ? kThin : fail(VAMD_EUNSUPPORTED, "%s: thin kernels do not cover Cin=%d Cout=%d stride=%d", who, g.Cin, g.Cout, g.stride);
+    if (algo == kMfma) return mfma_ok ? kMfma : fail(VAMD_EUNSUPPORTED, "%s: MFMA path does not cover Cin=%d Cout=%d", who, g.Cin, g.Cout);
+    if (thin_ok) return kThin;
+    return mfma_ok ? kMfma : kDirect;
+}
+}  // namespace
+
 extern "C" {
 
 int vamd_conv2d_fwd(const vamd_conv_desc* d, const void* x, const void* w, const float* bias,
@@ -46,18 +66,28 @@ int vamd_conv2d_fwd(const vamd_conv_desc* d, const void* x, const void* w, const
     VAMD_REQUIRE(x && w && y, "vamd_conv2d_fwd: null tensor");
     VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)y % 16 == 0,
                  "vamd_conv2d_fwd: tensors must be 16-byte aligned");
-    const bool mfma = d->algo != 1 && conv_fwd_mfma_supported(g, d->dtype);
-    if (d->algo == 2 && !mfma)
-        return fail(VAMD_EUNSUPPORTED, "vamd_conv2d_fwd: MFMA path does not cover Cin=%d Cout=%d", g.Cin, g.Cout);
-    if (mfma) return conv_fwd_mfma(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
+    const int a = pick(d->algo, conv_thin_supported(g, d->dtype), conv_fwd_mfma_supported(g, d->dtype), "vamd_conv2d_fwd", g);
+    if (a < 0) return a;
+    if (a == kThin) return conv_fwd_thin(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
+    if (a == kMfma) return conv_fwd_mfma(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
     return conv_fwd_direct(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
+}
+
+int vamd_conv2d_uses_mfma(const vamd_conv_desc* d, int pass) {
+    ConvGeom g;
+    if (conv_geom(d, &g, "vamd_conv2d_uses_mfma")) return 0;
+    int a;
+    if (pass == 0) a = pick(d->algo, conv_thin_supported(g, d->dtype), conv_fwd_mfma_supported(g, d->dtype), "", g);
+    else if (pass == 1) a = pick(d->algo, conv_thin_supported(transposed(g), d->dtype), conv_dgrad_mfma_supported(g, d->dtype), "", g);
+    else a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), "", g);
+    return a == kMfma ? 1 : 0;
 }
 
 size_t vamd_conv2d_dgrad_workspace(const vamd_conv_desc* d) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_dgrad_workspace")) return 0;
-    if (d->algo != 1 && conv_dgrad_mfma_supported(g, d->dtype)) return conv_dgrad_mfma_workspace(g, d->dtype);
-    return 0;
+    const int a = pick(d->algo, conv_thin_supported(transposed(g), d->dtype), conv_dgrad_mfma_supported(g, d->dtype), "", g);
+    return a == kMfma ? conv_dgrad_mfma_workspace(g, d->dtype) : 0;
 }
 
 int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, const void* add,
@@ -68,24 +98,32 @@ int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, 
     VAMD_REQUIRE(dy && w_t && dx, "vamd_conv2d_dgrad: null tensor");
     VAMD_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)w_t % 16 == 0 && (uintptr_t)dx % 16 == 0,
                  "vamd_conv2d_dgrad: tensors must be 16-byte aligned");
-    const bool mfma = d->algo != 1 && conv_dgrad_mfma_supported(g, d->dtype);
-    if (d->algo == 2 && !mfma)
-        return fail(VAMD_EUNSUPPORTED, "vamd_conv2d_dgrad: MFMA path does not cover Cin=%d Cout=%d", g.Cin, g.Cout);
-    if (mfma) return conv_dgrad_mfma(g, d->dtype, dy, w_t, add, dx, workspace, workspace_bytes, as_stream(stream));
+    const int a = pick(d->algo, conv_thin_supported(transposed(g), d->dtype), conv_dgrad_mfma_supported(g, d->dtype), "vamd_conv2d_dgrad", g);
+    if (a < 0) return a;
+    if (a == kThin) return conv_dgrad_thin(g, d->dtype, dy, w_t, add, dx, as_stream(stream));
+    if (a == kMfma) return conv_dgrad_mfma(g, d->dtype, dy, w_t, add, dx, workspace, workspace_bytes, as_stream(stream));
     return conv_dgrad_direct(g, d->dtype, dy, w_t, add, dx, as_stream(stream));
 }
 
-int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
+size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d) {
+    ConvGeom g;
+    if (conv_geom(d, &g, "vamd_conv2d_wgrad_workspace")) return 0;
+    const int a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), "", g);
+    return a == kThin ? conv_wgrad_thin_workspace(g, d->dtype) : 0;
+}
+
+int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
+                      size_t workspace_bytes, void* stream) {
     ConvGeom g;
     int rc = conv_geom(d, &g, "vamd_conv2d_wgrad");
     if (rc) return rc;
     VAMD_REQUIRE(dy && x && dw, "vamd_conv2d_wgrad: null tensor");
     VAMD_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dw % 16 == 0,
                  "vamd_conv2d_wgrad: tensors must be 16-byte aligned");
-    const bool mfma = d->algo != 1 && conv_wgrad_mfma_supported(g, d->dtype);
-    if (d->algo == 2 && !mfma)
-        return fail(VAMD_EUNSUPPORTED, "vamd_conv2d_wgrad: MFMA path does not cover Cin=%d Cout=%d", g.Cin, g.Cout);
-    if (mfma) return conv_wgrad_mfma(g, d->dtype, dy, x, dw, as_stream(stream));
+    const int a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), "vamd_conv2d_wgrad", g);
+    if (a < 0) return a;
+    if (a == kThin) return conv_wgrad_thin(g, d->dtype, dy, x, dw, workspace, workspace_bytes, as_stream(stream));
+    if (a == kMfma) return conv_wgrad_mfma(g, d->dtype, dy, x, dw, as_stream(stream));
     return conv_wgrad_direct(g, d->dtype, dy, x, dw, as_stream(stream));
 }
 

@@ -23,6 +23,17 @@ int conv_dgrad_direct(const ConvGeom& g, int dtype, const void* dy, const void* 
 int conv_wgrad_direct(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw,
                       hipStream_t st);
 
+// thin-channel kernels (conv_thin.hip): layers with <= 4 input or output channels, stride 1
+bool conv_thin_supported(const ConvGeom& g, int dtype);
+int conv_fwd_thin(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
+                  const float* temb, const void* res, const void* res2, void* y, hipStream_t st);
+int conv_dgrad_thin(const ConvGeom& g, int dtype, const void* dy, const void* wt, const void* add, void* dx,
+                    hipStream_t st);
+bool conv_wgrad_thin_supported(const ConvGeom& g, int dtype);
+size_t conv_wgrad_thin_workspace(const ConvGeom& g, int dtype);
+int conv_wgrad_thin(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, void* workspace,
+                    size_t workspace_bytes, hipStream_t st);
+
 // MFMA implicit-GEMM kernels (conv_mfma.hip).  *_supported says whether the shape is covered.
 bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype);
 int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,

@@ -10,11 +10,33 @@ constexpr int kStatsBlock = 256;
 constexpr int kStatsRowsPerChunk = 256;
 constexpr int kStatsMaxChunks = 512;
 
-static inline int stats_chunks(int64_t R) {
+// chunks per group: at least kStatsRowsPerChunk rows each, and about 2048 workgroups over all groups
+static inline int stats_chunks(int64_t R, int G) {
     int64_t n = (R + kStatsRowsPerChunk - 1) / kStatsRowsPerChunk;
+    int64_t cap = 2048 / (G > 0 ? G : 1);
+    if (cap < 1) cap = 1;
+    if (cap > kStatsMaxChunks) cap = kStatsMaxChunks;
+    if (n > cap) n = cap;
     if (n < 1) n = 1;
-    if (n > kStatsMaxChunks) n = kStatsMaxChunks;
     return (int)n;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one wave per channel: sums component 0 and 1 of partial[part][C][2] over `nparts` parts
+__device__ __forceinline__ void reduce_parts(const float* __restrict__ partial, int nparts, int C, int c,
+                                             double& s1, double& s2) {
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x & 63; k < nparts; k += 64) {
+        a += (double)partial[((int64_t)k * C + c) * 2 + 0];
+        b += (double)partial[((int64_t)k * C + c) * 2 + 1];
+    }
+    s1 = wave_sum_d(a);
+    s2 = wave_sum_d(b);
 }
 
 struct NormBwdArgs {
@@ -114,15 +136,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nchunk
                                    float* running_var, int64_t* nbt, float momentum, float eps,
                                    int training, float* scale, float* shift, float* mean,
                                    float* rstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;                      // one wave per channel
     float mu, var;
     if (training) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
-            s1 += (double)partial[((int64_t)k * C + c) * 2 + 0];
-            s2 += (double)partial[((int64_t)k * C + c) * 2 + 1];
-        }
+        double s1, s2;
+        reduce_parts(partial, nchunk, C, c, s1, s2);
+        if (threadIdx.x != 0) return;
         const double m = s1 / count;
         double v = s2 / count - m * m;
         if (v < 0.0) v = 0.0;
@@ -135,6 +154,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nchunk
         }
         if (c == 0 && nbt) nbt[0] += 1;
     } else {
+        if (threadIdx.x != 0) return;
         mu = running_mean[c];
         var = running_var[c];
     }
@@ -181,13 +201,10 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nc
                                        double count, const float* __restrict__ scale,
                                        float* dgamma, float* dbeta, float* cA, float* cB,
                                        float* cC) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        s1 += (double)partial[((int64_t)k * C + c) * 2 + 0];
-        s2 += (double)partial[((int64_t)k * C + c) * 2 + 1];
-    }
+    const int c = blockIdx.x;                      // one wave per channel
+    double s1, s2;
+    reduce_parts(partial, nchunk, C, c, s1, s2);
+    if (threadIdx.x != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     const double sc = (double)scale[c];
@@ -226,22 +243,19 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ partial, int nchunk
     }
 }
 
-// thread per c: per_g[g][c] = sum_chunk comp, total[c] = sum_g; comp 0 -> out0, comp 1 -> out1
+// one wave per channel: per_g0[g][c] = sum over chunks of component 0, total0/1[c] = sums over g too
 __global__ void sum_over_g_kernel(const float* __restrict__ partial, int nchunk, int G, int C,
                                   float* per_g0, float* total0, float* total1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double t0 = 0.0, t1 = 0.0;
     for (int g = 0; g < G; ++g) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
-            s0 += (double)partial[(((int64_t)g * nchunk + k) * C + c) * 2 + 0];
-            s1 += (double)partial[(((int64_t)g * nchunk + k) * C + c) * 2 + 1];
-        }
-        if (per_g0) per_g0[(int64_t)g * C + c] = (float)s0;
+        double s0, s1;
+        reduce_parts(partial + (int64_t)g * nchunk * C * 2, nchunk, C, c, s0, s1);
+        if (per_g0 && threadIdx.x == 0) per_g0[(int64_t)g * C + c] = (float)s0;
         t0 += s0;
         t1 += s1;
     }
+    if (threadIdx.x != 0) return;
     if (total0) total0[c] = (float)t0;
     if (total1) total1[c] = (float)t1;
 }
@@ -329,7 +343,7 @@ template <typename T, int MODE>
 static int launch_stats(const char* name, const T* x, NormBwdArgs a, float* partial, int G,
                         int64_t R, int C, hipStream_t st) {
     constexpr int VEC = Vec16<T>::N;
-    const int nchunk = stats_chunks(R);
+    const int nchunk = stats_chunks(R, G);
     dim3 grid(nchunk, G);
     const bool vec = (C % VEC == 0) && (C / VEC <= kStatsBlock);
     if (vec) {
@@ -353,7 +367,7 @@ using namespace vamd;
 
 extern "C" {
 
-int vamd_stats_chunks(int64_t R) { return stats_chunks(R); }
+int vamd_stats_chunks(int64_t R, int G) { return stats_chunks(R, G); }
 
 int vamd_chan_stats(const void* x, float* partial, int G, int64_t R, int C, int dtype, void* stream) {
     VAMD_REQUIRE(x && partial && G > 0 && G <= 65535 && R > 0 && C > 0, "vamd_chan_stats: bad argument");
@@ -390,7 +404,7 @@ int vamd_bn_finalize(const float* partial, int nchunk, int C, int64_t count, con
     VAMD_REQUIRE(gamma && beta && scale && shift && mean && rstd && C > 0, "vamd_bn_finalize: null pointer");
     VAMD_REQUIRE(training ? (partial && nchunk > 0 && count > 0) : (running_mean && running_var),
                  "vamd_bn_finalize: training needs partial sums, eval needs running statistics");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream),
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream),
                        partial, nchunk, C, (double)count, gamma, beta, running_mean, running_var,
                        num_batches_tracked, momentum, eps, training, scale, shift, mean, rstd);
     VAMD_LAUNCH_OK("vamd_bn_finalize");
@@ -437,7 +451,7 @@ int vamd_bn_bwd_finalize(const float* partial, int nchunk, int C, int64_t count,
                          float* dgamma, float* dbeta, float* cA, float* cB, float* cC, void* stream) {
     VAMD_REQUIRE(partial && scale && dgamma && dbeta && cA && cB && cC && nchunk > 0 && C > 0 && count > 0,
                  "vamd_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream),
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream),
                        partial, nchunk, C, (double)count, scale, dgamma, dbeta, cA, cB, cC);
     VAMD_LAUNCH_OK("vamd_bn_bwd_finalize");
     return 0;
@@ -452,7 +466,7 @@ int vamd_gn_bwd_finalize(const float* partial, int nchunk, int B, int C, int gro
     const int total = B * groups;
     hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((total + 63) / 64), dim3(64), 0, as_stream(stream),
                        partial, nchunk, B, C, groups, (double)HW * (C / groups), gamma, rstd, cA, cB, cC);
-    hipLaunchKernelGGL(sum_over_g_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), partial,
+    hipLaunchKernelGGL(sum_over_g_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial,
                        nchunk, B, C, (float*)nullptr, dbeta, dgamma);
     VAMD_LAUNCH_OK("vamd_gn_bwd_finalize");
     return 0;
@@ -488,7 +502,7 @@ int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const f
 int vamd_sum_finalize(const float* partial, int nchunk, int G, int C, float* per_g, float* total,
                       void* stream) {
     VAMD_REQUIRE(partial && nchunk > 0 && G > 0 && C > 0 && (per_g || total), "vamd_sum_finalize: bad argument");
-    hipLaunchKernelGGL(sum_over_g_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), partial,
+    hipLaunchKernelGGL(sum_over_g_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial,
                        nchunk, G, C, per_g, total, (float*)nullptr);
     VAMD_LAUNCH_OK("vamd_sum_finalize");
     return 0;

@@ -66,12 +66,27 @@ class _Conv:
             return (H - 1) // 2 + 1, (W - 1) // 2 + 1
         return H, W
 
+    def _timed(self, which, B, H, W):
+        """Benchmark hook: when eng.profile is a list, bracket MFMA launches with HIP events."""
+        prof = self.eng.profile
+        if prof is None or not lib.vamd_conv2d_uses_mfma(C.byref(self.desc(B, H, W)), which):
+            return None
+        Ho, Wo = self.out_hw(H, W)
+        flops = 2.0 * B * Ho * Wo * self.cin * self.cout * self.k * self.k
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        prof.append(("tn" if which == 2 else "nt", flops, e0, e1))
+        return e1
+
     def fwd(self, x, temb=None, res=None, res2=None, bias=True):
         B, H, W, _ = x.shape
         Ho, Wo = self.out_hw(H, W)
         y = torch.empty((B, Ho, Wo, self.cout), dtype=self.eng.dtype, device=x.device)
+        ev = self._timed(0, B, H, W)
         call("vamd_conv2d_fwd", C.byref(self.desc(B, H, W)), _ptr(x), _ptr(self.wf),
              _ptr(self.b) if bias else None, _ptr(temb), _ptr(res), _ptr(res2), _ptr(y), _stream())
+        if ev is not None:
+            ev.record()
         return y
 
     def dgrad(self, dy, in_shape, add=None):
@@ -80,17 +95,28 @@ class _Conv:
         dx = torch.empty(in_shape, dtype=self.eng.dtype, device=dy.device)
         nbytes = lib.vamd_conv2d_dgrad_workspace(C.byref(d))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device) if nbytes else None
+        ev = self._timed(1, B, H, W)
         call("vamd_conv2d_dgrad", C.byref(d), _ptr(dy), _ptr(self.wd), _ptr(add), _ptr(dx), _ptr(ws),
              nbytes, _stream())
+        if ev is not None:
+            ev.record()
         return dx
 
     def wgrad(self, dy, x):
         B, H, W, _ = x.shape
+        ev = self._timed(2, B, H, W)
+        d = self.desc(B, H, W)
+        nbytes = lib.vamd_conv2d_wgrad_workspace(C.byref(d))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
         if self.k == 1:
-            call("vamd_conv2d_wgrad", C.byref(self.desc(B, H, W)), _ptr(dy), _ptr(x), _ptr(self.gw), _stream())
+            call("vamd_conv2d_wgrad", C.byref(d), _ptr(dy), _ptr(x), _ptr(self.gw), _ptr(ws), nbytes, _stream())
+            if ev is not None:
+                ev.record()
         else:
             tmp = torch.empty(self.gw.numel(), dtype=torch.float32, device=x.device)
-            call("vamd_conv2d_wgrad", C.byref(self.desc(B, H, W)), _ptr(dy), _ptr(x), _ptr(tmp), _stream())
+            call("vamd_conv2d_wgrad", C.byref(d), _ptr(dy), _ptr(x), _ptr(tmp), _ptr(ws), nbytes, _stream())
+            if ev is not None:
+                ev.record()
             call("vamd_unpack_wgrad", _ptr(tmp), _ptr(self.gw), self.cout, self.cin, self.k, _stream())
 
 
@@ -136,7 +162,7 @@ class _Norm:
             call("vamd_bn_finalize", None, 0, Cc, 0, _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm),
                  _ptr(self.rv), None, BN_MOMENTUM, BN_EPS, 0, _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs), _stream())
         else:
-            nchunk = lib.vamd_stats_chunks(R)
+            nchunk = lib.vamd_stats_chunks(R, G)
             part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=dev)
             call("vamd_chan_stats", _ptr(x), _ptr(part), G, R, Cc, e.dt, _stream())
             if self.bn:
@@ -156,7 +182,7 @@ class _Norm:
         e, dev = self.eng, x.device
         G, R = (1, B * H * W) if self.bn else (B, H * W)
         sc, sh, mu, rs = coef[0], coef[1], coef[2], coef[3]
-        nchunk = lib.vamd_stats_chunks(R)
+        nchunk = lib.vamd_stats_chunks(R, G)
         part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=dev)
         call("vamd_norm_bwd_stats", _ptr(dy), _ptr(x), _ptr(mask), _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs),
              self.slope, _ptr(part), G, R, Cc, e.dt, _stream())
@@ -181,7 +207,7 @@ def _chan_sums(eng, t, per_image: bool):
     """Per-channel sums of an NHWC tensor: returns (per_image [B][C] or None, total [C])."""
     B, H, W, Cc = t.shape
     G, R = (B, H * W) if per_image else (1, B * H * W)
-    nchunk = lib.vamd_stats_chunks(R)
+    nchunk = lib.vamd_stats_chunks(R, G)
     part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=t.device)
     call("vamd_chan_stats", _ptr(t), _ptr(part), G, R, Cc, eng.dt, _stream())
     return part, nchunk, G
@@ -377,8 +403,28 @@ class Engine:
                 p.grad = g
                 self._p[name], self._g[name] = view, g
                 self.param_slices[name] = (off, n)
-        self._b = dict(module.named_buffers())
+        # BatchNorm buffers likewise: one fp32 arena (running_mean / running_var) and one int64
+        # arena (num_batches_tracked), so a data-parallel buffer broadcast is two collectives
+        bufs = list(module.named_buffers())
+        fl = [(n, b) for n, b in bufs if b.dtype == torch.float32]
+        it = [(n, b) for n, b in bufs if b.dtype == torch.int64]
+        assert len(fl) + len(it) == len(bufs), "unexpected buffer dtype"
+        self.flat_b = torch.zeros(sum((b.numel() + 3) // 4 * 4 for _, b in fl), dtype=torch.float32, device=self.device)
+        self.flat_nbt = torch.zeros(max(1, len(it)), dtype=torch.int64, device=self.device)
+        self._b = {}
+        with torch.no_grad():
+            off = 0
+            for n, b in fl:
+                view = self.flat_b[off:off + b.numel()].view(b.shape)
+                view.copy_(b)
+                self._rebind_buffer(module, n, view)
+                off += (b.numel() + 3) // 4 * 4
+            for i, (n, b) in enumerate(it):
+                view = self.flat_nbt[i:i + 1].view(b.shape)
+                view.copy_(b)
+                self._rebind_buffer(module, n, view)
         self._params = [p for _, p in params]
+        self.reducer = None               # set by vision_amd.parallel.DataParallel
         self._versions = None
 
         tf = plan.time_features
@@ -399,9 +445,33 @@ class Engine:
         # (models/ddpm.py:126-134) on the host, once
         freqs = torch.exp(torch.linspace(math.log(1.0), math.log(1000.0), plan.ch // 2))
         self.angular = (2.0 * math.pi * freqs).to(self.device)
+        self._lows = {spec.prefix: self._layer_low(spec.prefix) for spec in plan.layers}
+        self._lows["End"] = self._layer_low("End")
         self.dirty = True
         self.drop_generator = None
+        self.profile = None               # list -> receives (kind, flops, start, end) per MFMA conv launch
         self.debug_taps = None            # dict -> receives (output, folded skip) per layer (diagnostics)
+
+    def _rebind_buffer(self, module, name, view):
+        owner, _, leaf = name.rpartition(".")
+        sub = module.get_submodule(owner) if owner else module
+        sub._buffers[leaf] = view
+        self._b[name] = view
+
+    def layer_offsets(self):
+        """Arena offsets at which each layer's parameters start (creation order = arena order)."""
+        offs = set()
+        for name, (off, n) in self.param_slices.items():
+            parts = name.split(".")
+            key = ".".join(parts[:2]) if parts[0] in ("Downsampling", "Middle", "Upsampling") else parts[0]
+            offs.add((key, off))
+        first = {}
+        for key, off in offs:
+            first[key] = min(off, first.get(key, off))
+        return sorted(first.values())
+
+    def _layer_low(self, prefix):
+        return min(off for name, (off, n) in self.param_slices.items() if name.startswith(prefix + "."))
 
     # ---- parameter access for the layer objects
     def param(self, name):
@@ -480,10 +550,15 @@ class Engine:
         gradient arena (overwriting), returns nothing (the network input needs no gradient)."""
         tag, (h_end,) = tape.pop()
         assert tag == "end"
+        red = self.reducer
+        if red is not None:
+            red.begin()
         part, nchunk, G = _chan_sums(self, dout, False)
         call("vamd_sum_finalize", _ptr(part), nchunk, G, self.end.cout, None, _ptr(self.end.gb), _stream())
         self.end.wgrad(dout, h_end)
         g = self.end.dgrad(dout, h_end.shape)
+        if red is not None:
+            red.layer_done(self._lows["End"])
         nd, nm = self.n_down, self.n_mid
         n_up = len(self.layers) - nd - nm
         B = dout.shape[0]
@@ -503,11 +578,15 @@ class Engine:
                 # for up modules i-1 >= nd, hence extra is None and g_in is exactly that gradient.
                 dskip[nd - 1 - j] = g_in
             g = g_in
+            if red is not None:
+                red.layer_done(self._lows[layer.spec.prefix])
         tag, (emb, t1, temb) = tape.pop()
         assert tag == "temb"
         dt1 = torch.empty_like(t1)
         self.lin2.bwd(t1, dtemb, dx=dt1)
         self.lin1.bwd(emb, dt1, dx=None)
+        if red is not None:
+            red.finish()
         self.attach_grads()
 
     def attach_grads(self):

@@ -1,0 +1,250 @@
+"""A small stand-in for what the reference's `run.py` gets from pytorch-lightning: the fit /
+validate / test loops, the versioned log directory, callbacks and one-process-per-GPU data
+parallelism.  Only what `models/ddpm.py` and `run.py` of the reference rely on is implemented.
+
+Loop semantics (Lightning 2.0 defaults, which the reference inherits): training batches in train
+mode; after each epoch the LR scheduler steps and `on_train_epoch_end` runs; validation runs in
+eval mode under no_grad, its epoch mean of 'VL' feeds `callback_metrics`, then
+`on_validation_end` hooks (sampling, checkpointing) fire.
+"""
+import json
+import os
+import random
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .parallel import DataParallel, world_info
+
+_PRECISIONS = {"16-mixed": "bf16", "bf16-mixed": "bf16", "bf16": "bf16", "32": "fp32", "32-true": "fp32", 32: "fp32"}
+
+
+def seed_everything(seed: int, workers: bool = False):
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    return seed
+
+
+class DirLogger:
+    """`save_dir/name/version_N` directory layout of Lightning's TensorBoardLogger; scalars are
+    appended to metrics.jsonl (tensorboard is optional and not required)."""
+
+    def __init__(self, save_dir, name):
+        self.save_dir, self.name = save_dir, name
+        root = os.path.join(save_dir, name)
+        os.makedirs(root, exist_ok=True)
+        taken = [int(d.split("_")[1]) for d in os.listdir(root) if d.startswith("version_") and d.split("_")[1].isdigit()]
+        self.version = max(taken) + 1 if taken else 0
+        self.log_dir = os.path.join(root, f"version_{self.version}")
+
+    def log_metrics(self, metrics, step):
+        os.makedirs(self.log_dir, exist_ok=True)
+        with open(os.path.join(self.log_dir, "metrics.jsonl"), "a") as f:
+            f.write(json.dumps({"step": step, **{k: float(v) for k, v in metrics.items()}}) + "\n")
+
+
+class SyntheticImageFolder:
+    """ImageFolder-shaped batches without a dataset on disk: x float32 [B,3,P,P] uniform in [0,1)
+    (what Resize + ToTensor yield, reference dataloader.py:32-36), y int64 zeros; an 80/10/10
+    train/valid/test split like the reference's manual split (dataloader.py:56-64)."""
+
+    def __init__(self, patch_size=224, batch_size=32, length=256, seed=0, device="cpu", **_):
+        self.patch_size, self.batch_size, self.length, self.seed, self.device = patch_size, batch_size, length, seed, device
+        self.num_classes = 1
+
+    def setup(self, stage=None):
+        n_test = int(self.length * 0.1)
+        n_val = int(self.length * 0.1)
+        self.sizes = {"train": self.length - n_test - n_val, "valid": n_val, "test": n_test}
+
+    def _loader(self, split, rank=0, world=1):
+        n = self.sizes[split]
+        per_rank = n // world if split == "train" else n
+        g = torch.Generator(device="cpu").manual_seed(self.seed + 1000 * ("train", "valid", "test").index(split) + rank)
+        for i in range(0, per_rank - self.batch_size + 1, self.batch_size):
+            x = torch.rand((self.batch_size, 3, self.patch_size, self.patch_size), generator=g)
+            yield x.to(self.device, non_blocking=True), torch.zeros(self.batch_size, dtype=torch.int64, device=self.device)
+
+    def train_dataloader(self, rank=0, world=1):
+        return self._loader("train", rank, world)
+
+    def val_dataloader(self):
+        return self._loader("valid")
+
+    def test_dataloader(self):
+        return self._loader("test")
+
+
+class ImageFolderDataModule:
+    """PIL implementation of the reference's ImageFolderDataModule (dataloader.py:10-82) for the
+    use_manual_split layouts: class sub-directories of images, Resize((p, p)) + ToTensor, random
+    80/10/10 split, or train/valid/test sub-directories."""
+
+    EXT = (".jpg", ".jpeg", ".png", ".bmp", ".webp")
+
+    def __init__(self, data_dir, json_dir=None, patch_size=224, batch_size=32, num_workers=4, val_split=0.1,
+                 test_split=0.1, use_manual_split=False, device="cpu", **_):
+        self.data_dir, self.patch_size, self.batch_size = data_dir, patch_size, batch_size
+        self.val_split, self.test_split, self.use_manual_split, self.device = val_split, test_split, use_manual_split, device
+
+    def _scan(self, root):
+        classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
+        items = []
+        for ci, c in enumerate(classes):
+            for dp, _, files in sorted(os.walk(os.path.join(root, c))):
+                items += [(os.path.join(dp, f), ci) for f in sorted(files) if f.lower().endswith(self.EXT)]
+        return classes, items
+
+    def setup(self, stage=None):
+        if self.use_manual_split:
+            self.classes, items = self._scan(self.data_dir)
+            n = len(items)
+            n_test, n_val = int(n * self.test_split), int(n * self.val_split)
+            perm = torch.randperm(n).tolist()
+            pick = lambda idx: [items[i] for i in idx]
+            self.splits = {"train": pick(perm[:n - n_test - n_val]), "valid": pick(perm[n - n_test - n_val:n - n_test]),
+                           "test": pick(perm[n - n_test:])}
+        else:
+            self.splits = {}
+            for s in ("train", "valid", "test"):
+                self.classes, self.splits[s] = self._scan(os.path.join(self.data_dir, s))
+        self.num_classes = len(self.classes)
+
+    def _load(self, path):
+        from PIL import Image
+        img = Image.open(path).convert("RGB").resize((self.patch_size, self.patch_size), Image.BILINEAR)
+        return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+
+    def _loader(self, split, shuffle, rank=0, world=1):
+        items = self.splits[split]
+        order = torch.randperm(len(items)).tolist() if shuffle else list(range(len(items)))
+        order = order[rank::world] if world > 1 else order
+        for i in range(0, len(order), self.batch_size):
+            chunk = [items[j] for j in order[i:i + self.batch_size]]
+            x = torch.stack([self._load(p) for p, _ in chunk])
+            y = torch.tensor([c for _, c in chunk], dtype=torch.int64)
+            yield x.to(self.device), y.to(self.device)
+
+    def train_dataloader(self, rank=0, world=1):
+        return self._loader("train", True, rank, world)
+
+    def val_dataloader(self):
+        return self._loader("valid", False)
+
+    def test_dataloader(self):
+        return self._loader("test", False)
+
+
+class Trainer:
+    """fit / test loops with the handful of `pl.Trainer` arguments the reference's YAMLs use
+    (accelerator, devices, max_epochs, precision) plus max_steps / limit_* for smoke runs."""
+
+    def __init__(self, logger: Optional[DirLogger] = None, callbacks=(), max_epochs=1, precision="16-mixed",
+                 accelerator="gpu", devices=1, max_steps=-1, limit_val_batches=None, log_every_n_steps=1,
+                 enable_checkpointing=False, enable_progress_bar=False, num_nodes=1, **_):
+        self.logger, self.callbacks = logger, list(callbacks)
+        self.max_epochs, self.max_steps, self.limit_val_batches = max_epochs, max_steps, limit_val_batches
+        self.precision = _PRECISIONS.get(precision, "bf16")
+        self.current_epoch, self.global_step = 0, 0
+        self.callback_metrics = {}
+        self.global_rank, self.world_size = world_info()
+        self.lightning_module = None
+        self._epoch_sums = {}
+        self.dp: Optional[DataParallel] = None
+
+    @property
+    def is_global_zero(self):
+        return self.global_rank == 0
+
+    def record(self, name, value, on_step=False, on_epoch=True, sync_dist=False, **_):
+        v = value.detach() if torch.is_tensor(value) else torch.tensor(float(value))
+        if sync_dist and self.dp is not None and self.world_size > 1:
+            v = self.dp.all_reduce_scalar_mean(v)
+        s, c = self._epoch_sums.get(name, (0.0, 0))
+        self._epoch_sums[name] = (s + v, c + 1)          # stays on the device: no host sync per step
+
+    def _flush(self, names):
+        out = {}
+        for n in names:
+            if n in self._epoch_sums:
+                s, c = self._epoch_sums.pop(n)
+                out[n] = float(s) / c
+        return out
+
+    def _attach(self, model):
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))) if torch.cuda.is_available() else None
+        if device is None:
+            raise RuntimeError("vision_amd needs an MI355X (HIP device); no CPU path exists")
+        torch.cuda.set_device(device)
+        model.to(device)
+        model.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[self.precision]
+        model.trainer, model.logger = self, self.logger
+        self.lightning_module = model
+        self.dp = DataParallel(model)
+        return device
+
+    def fit(self, model, datamodule):
+        device = self._attach(model)
+        datamodule.device = device
+        datamodule.setup()
+        cfg = model.configure_optimizers()
+        if isinstance(cfg, tuple):
+            (opt,), scheds = cfg
+        else:
+            opt, scheds = cfg, []
+        for cb in self.callbacks:
+            if hasattr(cb, "on_train_start") and self.is_global_zero:
+                cb.on_train_start(self, model)
+        done = False
+        for epoch in range(self.max_epochs):
+            self.current_epoch = epoch
+            model.train()
+            for i, batch in enumerate(datamodule.train_dataloader(self.global_rank, self.world_size)):
+                self.dp.broadcast_buffers()
+                loss = model.training_step(batch, i)
+                loss.backward()
+                opt.step()
+                self.global_step += 1
+                if 0 < self.max_steps <= self.global_step:
+                    done = True
+                    break
+            for s in scheds:
+                s.step()
+            train_metrics = self._flush(["TL"])
+            model.on_train_epoch_end()
+            model.eval()
+            with torch.no_grad():
+                for i, batch in enumerate(datamodule.val_dataloader()):
+                    if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                        break
+                    model.validation_step(batch, i)
+            self.callback_metrics.update(train_metrics)
+            self.callback_metrics.update(self._flush(["VL"]))
+            if self.logger is not None and self.is_global_zero:
+                self.logger.log_metrics({**self.callback_metrics, "lr": opt.param_groups[0]["lr"]}, self.global_step)
+            with torch.no_grad():
+                model.on_validation_end()
+                if self.is_global_zero:
+                    for cb in self.callbacks:
+                        if hasattr(cb, "on_validation_end"):
+                            cb.on_validation_end(self, model)
+            if done:
+                break
+        return self
+
+    def test(self, model, dataloader, verbose=True):
+        if self.lightning_module is not model:
+            self._attach(model)
+        model.eval()
+        with torch.no_grad():
+            for i, batch in enumerate(dataloader):
+                model.test_step(batch, i)
+        out = self._flush(["TeL"])
+        if verbose and self.is_global_zero:
+            print(out)
+        return [out]
