@@ -140,12 +140,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ips = world * B * args.steps / elapsed
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     # roofline of the dominant kernel: MFMA implicit-GEMM "NT" (forward + input gradient)
     kinds = {}
-    for kind, flops, e0, e1 in prof:
+    per_shape = {}
+    for kind, flops, e0, e1, shape in prof:
         ms = e0.elapsed_time(e1)
+        f0, t0_, n0 = per_shape.get(shape, (0.0, 0.0, 0))
+        per_shape[shape] = (f0 + flops, t0_ + ms, n0 + 1)
         f, t, n = kinds.get(kind, (0.0, 0.0, 0))
         kinds[kind] = (f + flops, t + ms, n + 1)
     roof = None
@@ -161,6 +164,10 @@ def main():
         f, t, n = kinds["tn"]
         extra["wgrad_kernel"] = {"kernel": "conv_tn_mfma_kernel<bf16> (weight gradient)", "achieved_tflops": round(f / (t * 1e-3) / 1e12, 1),
                                  "launches": n, "avg_launch_ms": round(t / n, 4)}
+    if os.environ.get("VAMD_BENCH_LAYERS") and rank == 0:
+        for shape, (f, t, n) in sorted(per_shape.items(), key=lambda kv: -kv[1][1]):
+            print("layer %-52s calls %3d  %7.3f ms/call  %7.1f TFLOP/s  %5.1f%% of MFMA conv time" % (
+                str(shape), n, t / n, f / (t * 1e-3) / 1e12, 100 * t / sum(v[1] for v in per_shape.values())), file=sys.stderr)
     conv_ms = sum(v[1] for v in kinds.values()) / max(args.steps, 1)
     extra["mfma_conv_ms_per_step"] = round(conv_ms, 3)
 

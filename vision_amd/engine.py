@@ -75,7 +75,8 @@ class _Conv:
         flops = 2.0 * B * Ho * Wo * self.cin * self.cout * self.k * self.k
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        prof.append(("tn" if which == 2 else "nt", flops, e0, e1))
+        prof.append(("tn" if which == 2 else "nt", flops, e0, e1,
+                     (("fwd", "dgrad", "wgrad")[which], self.cin, self.cout, self.k, self.stride, int(self.up), B, H, W)))
         return e1
 
     def fwd(self, x, temb=None, res=None, res2=None, bias=True):
