@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--sample-steps", type=int, default=10)
+    ap.add_argument("--event-steps", type=int, default=None,
+                    help="timed steps whose MFMA conv launches are bracketed by HIP events (default: all)")
     return ap.parse_args()
 
 
@@ -128,13 +130,16 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    eng.profile = []          # (kind, flops, start_event, end_event) per MFMA conv launch
+    ev_steps = args.steps if args.event_steps is None else min(args.event_steps, args.steps)
+    prof = []                 # (kind, flops, start_event, end_event, shape) per MFMA conv launch
     t0 = time.perf_counter()
     for i in range(args.steps):
+        eng.profile = prof if i < ev_steps else None
         loss = step(args.warmup + i)
+    host_elapsed = time.perf_counter() - t0          # launches issued; the device may still be running
     fence()
     elapsed = time.perf_counter() - t0
-    prof, eng.profile = eng.profile, None
+    eng.profile = None
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -168,8 +173,9 @@ def main():
         for shape, (f, t, n) in sorted(per_shape.items(), key=lambda kv: -kv[1][1]):
             print("layer %-52s calls %3d  %7.3f ms/call  %7.1f TFLOP/s  %5.1f%% of MFMA conv time" % (
                 str(shape), n, t / n, f / (t * 1e-3) / 1e12, 100 * t / sum(v[1] for v in per_shape.values())), file=sys.stderr)
-    conv_ms = sum(v[1] for v in kinds.values()) / max(args.steps, 1)
+    conv_ms = sum(v[1] for v in kinds.values()) / max(ev_steps, 1)
     extra["mfma_conv_ms_per_step"] = round(conv_ms, 3)
+    extra["host_issue_ms_per_step"] = round(1e3 * host_elapsed / args.steps, 3)
 
     sampling = None
     if not args.no_sampling:

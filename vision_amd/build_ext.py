@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libvision_amd.so")
-SOURCES = ["elementwise.hip", "norm.hip", "conv_direct.hip", "conv_api.hip", "conv_mfma.hip", "conv_thin.hip", "probe.hip"]
+SOURCES = ["elementwise.hip", "norm.hip", "conv_direct.hip", "conv_api.hip", "conv_mfma.hip", "conv_thin.hip", "conv_thin_mfma.hip", "probe.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]

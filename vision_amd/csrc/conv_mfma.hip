@@ -51,8 +51,12 @@ struct Gather {
     int k, stride, pad;
     int shift;             // 1: stored row = u >> 1 (nearest upsample or zero insertion)
     int parity;            // 1: only even u, v carry data (zero insertion: dgrad of stride 2)
-    int M, Ktot;           // rows, and k*k*Cin
+    int M, Ktot;           // rows, and (tap rows)*(tap columns)*Cin
     FastDiv div_howo, div_wo;
+    // Sub-filter views (stride-2 input gradient, one launch per output parity class):
+    int ks;                // tap columns (k for a square filter); tap rows = Ktot / (ks * Cin)
+    int wr0, ws0, wstep, wk;   // tap (tr, ts) reads filter tap (wr0 + wstep*tr, ws0 + wstep*ts) of a wk x wk filter
+    int oH, oW, ostep, oph, opw;   // ostep = 2: row (b, ho, wo) is written to pixel (b, 2*ho + oph, 2*wo + opw) of an oH x oW image
 };
 
 struct Epilogue {
@@ -121,7 +125,7 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
     int c = f, tr = 0, ts = 0;
 #pragma unroll
     for (int it = 0; it < 2; ++it)
-        if (c >= gp.Cin) { c -= gp.Cin; if (++ts == gp.k) { ts = 0; ++tr; } }
+        if (c >= gp.Cin) { c -= gp.Cin; if (++ts == gp.ks) { ts = 0; ++tr; } }
 
     auto stage = [&](int buf) {
         unsigned char* sa = smem + buf * STAGE;
@@ -137,18 +141,19 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
             __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sa + (i * 256 + wave * 64) * 16), 16, 0, 0);
         }
         unsigned char* sb = sa + A_BYTES;
+        const int wf = ((gp.wr0 + gp.wstep * tr) * gp.wk + gp.ws0 + gp.wstep * ts) * gp.Cin + c;   // == f for a plain filter
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i) {
             const int n = n0 + srow + 32 * i;
             const bool ok = f_ok && n < N;
-            const T* src = ok ? w + ((int64_t)n * ldw + f) : reinterpret_cast<const T*>(g_zero_page);
+            const T* src = ok ? w + ((int64_t)n * ldw + wf) : reinterpret_cast<const T*>(g_zero_page);
             __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sb + (i * 256 + wave * 64) * 16), 16, 0, 0);
         }
         f += KSTEP;
         c += KSTEP;
 #pragma unroll
         for (int it = 0; it < 2; ++it)
-            if (c >= gp.Cin) { c -= gp.Cin; if (++ts == gp.k) { ts = 0; ++tr; } }
+            if (c >= gp.Cin) { c -= gp.Cin; if (++ts == gp.ks) { ts = 0; ++tr; } }
     };
 
     f32x4_t acc[4][NT];
@@ -236,7 +241,15 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
             }
 #pragma unroll
             for (int e = 0; e < PIECE; ++e) v[e] = v[e] * ep.alpha + bv[e];
-            const int64_t off = (int64_t)blockIdx.z * strideC + (int64_t)m * ldc + n;
+            int64_t orow = m;
+            if (gp.ostep) {
+                const uint32_t b = fdiv(m, gp.div_howo);
+                const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
+                const uint32_t ho = fdiv(rem, gp.div_wo);
+                const uint32_t wo = rem - ho * gp.Wo;
+                orow = ((int64_t)b * gp.oH + ho * gp.ostep + gp.oph) * gp.oW + wo * gp.ostep + gp.opw;
+            }
+            const int64_t off = (int64_t)blockIdx.z * strideC + orow * ldc + n;
             if (ep.temb) {
                 const uint32_t b = fdiv(m, gp.div_howo);
 #pragma unroll
@@ -271,50 +284,69 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
 // Weight gradient: dW[n][f] += sum over a slice of pixels m of dY[m][n] * Xg[m][f].
 // Both operands are "reduction-major" in memory (channel innermost), so their MFMA fragments are
 // read with the transposing LDS read ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (fp32).
-// LDS stage: dY tile [KP pixels][128 n] and Xg tile [KP pixels][128 f], rows of 128 elements.
+// LDS stage: dY tile [KP pixels][AN n] and Xg tile [KP pixels][BF f].  Two shapes:
+//   AN = 128, BF = 128: waves 2 x 2, each 64 n x 64 f                       (Cout >= 128, attention)
+//   AN =  64, BF = 192: waves 1 x 4, each 64 n x 48 f  (9*Cin is a multiple of 192 for Cin % 64 == 0)
 // Grid: (n tiles * f tiles, split-K slices); partial tiles are combined with fp32 atomics.
-template <typename T>
+template <int ROWB> __device__ __forceinline__ int tn_swizzle(int row) {
+    // XOR applied to the 16-byte piece index of a row so that the 8 rows x 32 bytes that 32 lanes
+    // fetch with one transposing read fall on 8 different bank groups
+    if constexpr (ROWB % 256 == 0) return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
+    else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;      // ROWB = odd multiple of 128
+}
+
+template <typename T, int AN, int BF>
 __global__ void __launch_bounds__(256, 2)
 conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x, int N, int lda, int ldc,
                     float* __restrict__ dw, int n_tiles, int f_tiles, int steps_per_slice,
                     int64_t strideA, int64_t strideB, int64_t strideC, int out_mode, void* yout,
                     float alpha) {
     constexpr int PIECE = ElemTraits<T>::PIECE;
-    constexpr int ROWB = 128 * sizeof(T);                 // bytes per LDS row (128 elements)
-    constexpr int PPR = ROWB / 16;                        // 16-byte pieces per row
-    constexpr int KP = 16384 / ROWB;                      // pixels per K-step: 64 (bf16) / 32 (fp32)
-    constexpr int TILE_BYTES = KP * ROWB;                 // 16 KiB per operand
-    constexpr int STAGE = 2 * TILE_BYTES;
-    constexpr int RPI = 256 / PPR;                        // rows covered by one 256-thread pass
-    constexpr int NPASS = KP / RPI;                       // passes per operand tile (4)
+    constexpr bool BF16 = sizeof(T) == 2;
+    constexpr int KP = BF16 ? 64 : 32;                    // pixels per K-step
+    constexpr int ROWB_A = AN * sizeof(T), ROWB_B = BF * sizeof(T);
+    constexpr int PPR_A = ROWB_A / 16, PPR_B = ROWB_B / 16;
+    constexpr int TILE_A = KP * ROWB_A, TILE_B = KP * ROWB_B;
+    constexpr int STAGE = TILE_A + TILE_B;
+    constexpr int NPASS_A = KP * PPR_A / 256, NPASS_B = KP * PPR_B / 256;
+    constexpr int WM = AN / 64, WN = 4 / WM;              // waves along n / along f
+    constexpr int NJ = BF / (16 * WN);                    // 16-wide f tiles per wave
+    static_assert(KP * PPR_A % 256 == 0 && KP * PPR_B % 256 == 0 && BF % (16 * WN) == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int bid = blockIdx.x;
     const int nt = bid / f_tiles, ft = bid - nt * f_tiles;
-    const int n0 = nt * 128, f0 = ft * 128;
+    const int n0 = nt * AN, f0 = ft * BF;
     dy += (int64_t)blockIdx.z * strideA;
     x += (int64_t)blockIdx.z * strideB;
 
-    // staging: this thread copies physical piece `slot` of rows srow + RPI*i
-    const int srow = tid / PPR, slot = tid % PPR;
-    // swizzle in units of 32 bytes (bf16: the transposing read fetches 4 rows x 32 B per 16 lanes)
-    auto sw_of = [](int row) -> int {
-        if constexpr (sizeof(T) == 2) return (((row & 3) | (((row >> 3) & 1) << 2)) << 1);
-        else return 0;
-    };
-    // (RPI is a multiple of 16, so sw_of(srow + RPI*i) == sw_of(srow))
-    const int piece = slot ^ sw_of(srow);
-    // operand A (dY): column n0 + piece*PIECE
-    const int an = n0 + piece * PIECE;
-    const bool an_ok = an + PIECE <= lda && an < N;
-    // operand B (Xg): flattened column f0 + piece*PIECE -> (tap, c), fixed for the whole kernel
-    const int bf = f0 + piece * PIECE;
-    const bool bf_ok = bf < gp.Ktot;
-    const int tap = bf / gp.Cin;
-    const int bc = bf - tap * gp.Cin;
-    const int tr = tap / gp.k, ts = tap - tr * gp.k;
+    // staging: in pass i this thread copies LDS piece i*256 + tid (the image of a direct-to-LDS
+    // load is lane-linear); the swizzle is applied to the piece it fetches
+    int a_row[NPASS_A], a_col[NPASS_A];                   // a_col < 0: nothing to fetch
+#pragma unroll
+    for (int i = 0; i < NPASS_A; ++i) {
+        const int pi = i * 256 + tid;
+        const int row = pi / PPR_A, slot = pi - row * PPR_A;
+        const int piece = BF16 ? (slot ^ tn_swizzle<ROWB_A>(row)) : slot;
+        const int an = n0 + piece * PIECE;
+        a_row[i] = row;
+        a_col[i] = (an + PIECE <= lda && an < N) ? an : -1;
+    }
+    int b_row[NPASS_B], b_tr[NPASS_B], b_ts[NPASS_B], b_c[NPASS_B];
+#pragma unroll
+    for (int i = 0; i < NPASS_B; ++i) {
+        const int pi = i * 256 + tid;
+        const int row = pi / PPR_B, slot = pi - row * PPR_B;
+        const int piece = BF16 ? (slot ^ tn_swizzle<ROWB_B>(row)) : slot;
+        const int bf = f0 + piece * PIECE;                // flattened column -> (tap, c)
+        const int tap = bf / gp.Cin;
+        b_row[i] = row;
+        b_c[i] = bf - tap * gp.Cin;
+        b_tr[i] = bf < gp.Ktot ? tap / gp.k : (1 << 20);  // out of range: the bounds test rejects it
+        b_ts[i] = tap - (tap / gp.k) * gp.k;
+    }
 
     const int step0 = blockIdx.y * steps_per_slice;
     const int total_steps = (gp.M + KP - 1) / KP;
@@ -323,66 +355,75 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 
     auto stage = [&](int buf, int step) {
         unsigned char* sa = smem + buf * STAGE;
-        unsigned char* sb = sa + TILE_BYTES;
+        unsigned char* sb = sa + TILE_A;
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const uint32_t m = (uint32_t)step * KP + srow + RPI * i;
-            const bool m_ok = m < (uint32_t)gp.M;
-            const T* srcA = (m_ok && an_ok) ? dy + ((int64_t)m * lda + an) : reinterpret_cast<const T*>(g_zero_page);
+        for (int i = 0; i < NPASS_A; ++i) {
+            const uint32_t m = (uint32_t)step * KP + a_row[i];
+            const T* srcA = (m < (uint32_t)gp.M && a_col[i] >= 0) ? dy + ((int64_t)m * lda + a_col[i])
+                                                                  : reinterpret_cast<const T*>(g_zero_page);
             __builtin_amdgcn_global_load_lds(GPTR(srcA), LPTR(sa + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NPASS_B; ++i) {
+            const uint32_t m = (uint32_t)step * KP + b_row[i];
             const uint32_t b = fdiv(m, gp.div_howo);
             const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
             const uint32_t ho = fdiv(rem, gp.div_wo);
-            const int u = (int)ho * gp.stride - gp.pad + tr;
-            const int v = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad + ts;
-            bool ok = m_ok && bf_ok && (unsigned)u < (unsigned)gp.He && (unsigned)v < (unsigned)gp.We;
+            const int u = (int)ho * gp.stride - gp.pad + b_tr[i];
+            const int v = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad + b_ts[i];
+            bool ok = m < (uint32_t)gp.M && (unsigned)u < (unsigned)gp.He && (unsigned)v < (unsigned)gp.We;
             if (gp.parity) ok = ok && (((u | v) & 1) == 0);
             const int hi = u >> gp.shift, wi = v >> gp.shift;
-            const T* srcB = ok ? x + ((((int64_t)b * gp.Hin + hi) * gp.Win + wi) * gp.ldx + bc)
+            const T* srcB = ok ? x + ((((int64_t)b * gp.Hin + hi) * gp.Win + wi) * gp.ldx + b_c[i])
                                : reinterpret_cast<const T*>(g_zero_page);
             __builtin_amdgcn_global_load_lds(GPTR(srcB), LPTR(sb + (i * 256 + wave * 64) * 16), 16, 0, 0);
         }
     };
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
         const unsigned char* sa = smem + buf * STAGE;
-        const unsigned char* sb = sa + TILE_BYTES;
-        if constexpr (sizeof(T) == 2) {
+        const unsigned char* sb = sa + TILE_A;
+        if constexpr (BF16) {
             // 16x16x32 per k-step of 32 pixels; lane l supplies row k0 + ((l&15)>>2), cols c0 + 4*(l&3)
             const int q = (lane & 15) >> 2, p = lane & 3, g = lane >> 4;
 #pragma unroll
             for (int ks = 0; ks < KP / 32; ++ks) {
-                bf16x8_t a[4], b[4];
+                bf16x8_t a[4], b[NJ];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int row = ks * 32 + g * 8 + h * 4 + q;
-                    const int sw = sw_of(row);
+                    const int swa = tn_swizzle<ROWB_A>(row), swb = tn_swizzle<ROWB_B>(row);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int col = wm * 64 + i * 16 + p * 4;            // element column
-                        const int pc = (col >> 3) ^ sw;                      // physical 16-byte piece
+                        const int pc = (col >> 3) ^ swa;                     // physical 16-byte piece
                         const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t*)(sa + row * ROWB + pc * 16 + (col & 7) * 2));
-                        const int colb = wn * 64 + i * 16 + p * 4;
-                        const int pcb = (colb >> 3) ^ sw;
-                        const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t*)(sb + row * ROWB + pcb * 16 + (colb & 7) * 2));
+                            (__attribute__((address_space(3))) s16x4_t*)(sa + row * ROWB_A + pc * 16 + (col & 7) * 2));
                         const bf16x4_t fa = __builtin_bit_cast(bf16x4_t, va);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = fa[e];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int colb = wn * (16 * NJ) + j * 16 + p * 4;
+                        const int pcb = (colb >> 3) ^ swb;
+                        const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t*)(sb + row * ROWB_B + pcb * 16 + (colb & 7) * 2));
                         const bf16x4_t fb = __builtin_bit_cast(bf16x4_t, vb);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { a[i][h * 4 + e] = fa[e]; b[i][h * 4 + e] = fb[e]; }
+                        for (int e = 0; e < 4; ++e) b[j][h * 4 + e] = fb[e];
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         } else {
@@ -392,16 +433,17 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 #pragma unroll
             for (int ks = 0; ks < KP / 4; ++ks) {
                 const int row = ks * 4 + g;
-                float a[4], b[4];
+                float a[4], b[NJ];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[i] = *reinterpret_cast<const float*>(sa + row * ROWB + (wm * 64 + i * 16 + fr) * 4);
-                    b[i] = *reinterpret_cast<const float*>(sb + row * ROWB + (wn * 64 + i * 16 + fr) * 4);
-                }
+                for (int i = 0; i < 4; ++i)
+                    a[i] = *reinterpret_cast<const float*>(sa + row * ROWB_A + (wm * 64 + i * 16 + fr) * 4);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    b[j] = *reinterpret_cast<const float*>(sb + row * ROWB_B + (wn * (16 * NJ) + j * 16 + fr) * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
@@ -426,8 +468,8 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int fcol = f0 + wn * 64 + j * 16 + fr;
+            for (int j = 0; j < NJ; ++j) {
+                const int fcol = f0 + wn * (16 * NJ) + j * 16 + fr;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nrow = n0 + wm * 64 + i * 16 + fq * 4 + r;
@@ -441,8 +483,8 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int fcol = f0 + wn * 64 + j * 16 + fr;
+            for (int j = 0; j < NJ; ++j) {
+                const int fcol = f0 + wn * (16 * NJ) + j * 16 + fr;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nrow = n0 + wm * 64 + i * 16 + fq * 4 + r;
@@ -462,6 +504,8 @@ static Gather make_gather(int Hin, int Win, int Cin, int He, int We, int Ho, int
     g.M = (int)M; g.Ktot = k * k * Cin;
     g.div_howo = make_fastdiv((uint32_t)(Ho * Wo));
     g.div_wo = make_fastdiv((uint32_t)Wo);
+    g.ks = k; g.wr0 = 0; g.ws0 = 0; g.wstep = 1; g.wk = k;
+    g.oH = 0; g.oW = 0; g.ostep = 0; g.oph = 0; g.opw = 0;
     return g;
 }
 
@@ -520,6 +564,7 @@ int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, co
 }
 
 bool conv_dgrad_mfma_supported(const ConvGeom& g, int dtype) {
+    if (g.stride == 2 && g.k != 3) return false;       // a strided 1x1 leaves whole parity classes without taps
     const int64_t rows = (int64_t)g.B * g.He * g.We;
     return nt_shape_ok(g.Cout, g.Cin, rows, dtype);
 }
@@ -564,14 +609,44 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
                     void* dx, void* workspace, size_t workspace_bytes, hipStream_t st) {
     // The input gradient is itself a convolution over dY with the flipped, transposed filter:
     //   stride 1: plain 3x3 pad 1 (or 1x1) over dY at the output resolution;
-    //   stride 2: dY is read through zero insertion (only even tap coordinates carry data);
-    //   upsample: stride-1 result at the upsampled resolution, then a 2x2 sum.
+    //   upsample: stride-1 result at the upsampled resolution, then a 2x2 sum;
+    //   stride 2: input pixel (h, w) only meets the filter taps r = h + pad (mod 2), s likewise, so
+    //             each of the 4 parity classes of (h, w) is a small dense convolution of its own
+    //             (1, 2, 2 and 4 of the 9 taps for a 3x3 pad-1 filter) over dY: no multiplications
+    //             by inserted zeros.
+    if (g.stride == 2) {
+        const int padT = g.k - 1 - g.pad;
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                const int Hc = (g.H - ph + 1) / 2, Wc = (g.W - pw + 1) / 2;     // pixels of this class
+                if (Hc <= 0 || Wc <= 0) continue;
+                // flipped-filter tap r reads dY row (h + r - padT) / 2, which must be an integer
+                const int r0 = (ph + padT) & 1, s0 = (pw + padT) & 1;
+                const int kr = (g.k - r0 + 1) / 2, kc = (g.k - s0 + 1) / 2;
+                if (kr <= 0 || kc <= 0) {
+                    return fail(VAMD_EUNSUPPORTED, "conv_dgrad_mfma: stride-2 class without taps (k=%d)", g.k);
+                }
+                // dY row for class row ho and tap index tr: ho + tr + (ph + r0 - padT) / 2 (exact division)
+                const int offr = (ph + r0 - padT) / 2, offs = (pw + s0 - padT) / 2;
+                Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, Hc, Wc, 1, 1, -offr, 0, 0, (int64_t)g.B * Hc * Wc);
+                if (offr != offs)
+                    return fail(VAMD_EUNSUPPORTED, "conv_dgrad_mfma: unsupported stride-2 padding");
+                gp.ks = kc;
+                gp.Ktot = kr * kc * g.Cout;
+                gp.wr0 = r0; gp.ws0 = s0; gp.wstep = 2; gp.wk = g.k;
+                gp.oH = g.H; gp.oW = g.W; gp.ostep = 2; gp.oph = ph; gp.opw = pw;
+                Epilogue ep{nullptr, nullptr, add, nullptr, 1.0f, 0};
+                const int ldw = g.k * g.k * g.Cout;
+                int rc = dtype == VAMD_BF16 ? run_nt<bf16_t>(gp, dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st)
+                                            : run_nt<float>(gp, dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st);
+                if (rc) return rc;
+            }
+        return 0;
+    }
     const int rowsH = g.up ? g.He : g.H, rowsW = g.up ? g.We : g.W;   // extents the GEMM rows enumerate
     const int64_t rows = (int64_t)g.B * rowsH * rowsW;
-    const int dil = g.stride == 2 ? 1 : 0;
-    const int He = dil ? 2 * g.Ho - 1 : g.Ho, We = dil ? 2 * g.Wo - 1 : g.Wo;
     const int padT = g.k - 1 - g.pad;
-    Gather gp = make_gather(g.Ho, g.Wo, g.Cout, He, We, rowsH, rowsW, g.k, 1, padT, dil, dil, rows);
+    Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, rowsH, rowsW, g.k, 1, padT, 0, 0, rows);
     void* out = dx;
     const void* res = add;
     if (g.up) {
@@ -604,18 +679,18 @@ bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype) {
     return tn_shape_ok(g.Cin, g.Cout, g.M, dtype);
 }
 
-template <typename T>
-static int launch_tn(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
-                     int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, hipStream_t st) {
-    constexpr int LDS = 2 * 2 * 16384;
+template <typename T, int AN, int BF>
+static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
+                           int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, hipStream_t st) {
+    constexpr int KP = sizeof(T) == 2 ? 64 : 32;
+    constexpr int LDS = 2 * KP * (AN + BF) * (int)sizeof(T);
     static bool configured = false;
     if (!configured) {
-        int rc = set_lds_limit(conv_tn_mfma_kernel<T>, LDS, "conv_tn_mfma");
+        int rc = set_lds_limit(conv_tn_mfma_kernel<T, AN, BF>, LDS, "conv_tn_mfma");
         if (rc) return rc;
         configured = true;
     }
-    constexpr int KP = 16384 / (128 * sizeof(T));
-    const int n_tiles = (N + 127) / 128, f_tiles = (gp.Ktot + 127) / 128;
+    const int n_tiles = (N + AN - 1) / AN, f_tiles = (gp.Ktot + BF - 1) / BF;
     const int total_steps = (gp.M + KP - 1) / KP;
     int slices = 1;
     if (out_mode == 0) {
@@ -629,10 +704,19 @@ static int launch_tn(const Gather& gp, const T* dy, const T* x, int N, int lda, 
     const int steps_per = (total_steps + slices - 1) / slices;
     slices = (total_steps + steps_per - 1) / steps_per;
     dim3 grid(n_tiles * f_tiles, slices, batch);
-    hipLaunchKernelGGL((conv_tn_mfma_kernel<T>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
+    hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
                        f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha);
     VAMD_LAUNCH_OK("conv_tn_mfma");
     return 0;
+}
+
+template <typename T>
+static int launch_tn(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
+                     int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, hipStream_t st) {
+    // narrow outputs (Cout <= 64): a 64 x 192 tile wastes no MFMA rows and 192 divides 9*Cin
+    if (out_mode == 0 && N <= 64 && gp.Ktot >= 192)
+        return launch_tn_shape<T, 64, 192>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, st);
+    return launch_tn_shape<T, 128, 128>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, st);
 }
 
 int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, hipStream_t st) {

@@ -34,6 +34,17 @@ size_t conv_wgrad_thin_workspace(const ConvGeom& g, int dtype);
 int conv_wgrad_thin(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, void* workspace,
                     size_t workspace_bytes, hipStream_t st);
 
+// bf16 thin-channel kernels on the matrix cores (conv_thin_mfma.hip); conv_thin.hip dispatches to them
+bool thin_in_mfma_ok(const ConvGeom& g);
+int thin_in_mfma(const ConvGeom& g, const void* x, const void* w, const float* bias, const float* temb,
+                 const void* res, const void* res2, void* y, hipStream_t st);
+bool thin_out_mfma_ok(const ConvGeom& g);
+int thin_out_mfma(const ConvGeom& g, const void* x, const void* w, const float* bias, const float* temb,
+                  const void* res, const void* res2, void* y, hipStream_t st);
+bool thin_wgrad_mfma_ok(const ConvGeom& g);
+size_t thin_wgrad_mfma_workspace(const ConvGeom& g);
+int thin_wgrad_mfma(const ConvGeom& g, const void* dy, const void* x, float* dw, void* workspace, hipStream_t st);
+
 // MFMA implicit-GEMM kernels (conv_mfma.hip).  *_supported says whether the shape is covered.
 bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype);
 int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,

@@ -446,6 +446,10 @@ bool conv_thin_supported(const ConvGeom& g, int dtype) {
 
 int conv_fwd_thin(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
                   const float* temb, const void* res, const void* res2, void* y, hipStream_t st) {
+    if (dtype == VAMD_BF16) {
+        if (g.Cin <= kSm && thin_in_mfma_ok(g)) return thin_in_mfma(g, x, w, bias, temb, res, res2, y, st);
+        if (g.Cin > kSm && thin_out_mfma_ok(g)) return thin_out_mfma(g, x, w, bias, temb, res, res2, y, st);
+    }
     VAMD_DISPATCH(dtype, "conv_fwd_thin", {
         if (g.Cin <= kSm) {
             const dim3 grid((unsigned)((g.M + 255) / 256));
@@ -502,6 +506,7 @@ bool conv_wgrad_thin_supported(const ConvGeom& g, int dtype) {
 }
 
 size_t conv_wgrad_thin_workspace(const ConvGeom& g, int dtype) {
+    if (dtype == VAMD_BF16 && thin_wgrad_mfma_ok(g)) return thin_wgrad_mfma_workspace(g);
     const int nb = thin_wgrad_blocks(g);
     if (both_thin(g)) return (size_t)nb * g.k * g.k * kSm * kSm * sizeof(float);
     const int vec = dtype == VAMD_BF16 ? 8 : 4;
@@ -533,6 +538,7 @@ int conv_wgrad_thin(const ConvGeom& g, int dtype, const void* dy, const void* x,
                     size_t workspace_bytes, hipStream_t st) {
     if (!workspace || workspace_bytes < conv_wgrad_thin_workspace(g, dtype))
         return fail(VAMD_EINVAL, "conv_wgrad_thin: needs %zu workspace bytes", conv_wgrad_thin_workspace(g, dtype));
+    if (dtype == VAMD_BF16 && thin_wgrad_mfma_ok(g)) return thin_wgrad_mfma(g, dy, x, dw, workspace, st);
     float* slab = reinterpret_cast<float*>(workspace);
     const bool wide_out = g.Cin <= kSm;
     VAMD_DISPATCH(dtype, "conv_wgrad_thin", {

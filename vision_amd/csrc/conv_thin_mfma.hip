@@ -1,0 +1,573 @@
+// Thin-channel convolutions on the matrix cores (bf16).
+//
+// The layers that touch the 3-channel image at full resolution move a 64-channel tensor through
+// HBM once and do almost no arithmetic per byte, yet on the vector ALUs they are compute-bound
+// (64 x 27 FMAs per pixel).  Mapping them onto v_mfma_f32_16x16x32_bf16 with the thin side padded
+// inside the MFMA tile makes the arithmetic free and leaves the wide tensor's HBM traffic:
+//
+//   thin_in    Cin <= 4 -> Cout (K*K*Cin <= 32): one MFMA k-step holds the whole filter.  The
+//              input window of a 16x16 pixel tile sits zero-padded in LDS; a lane builds its
+//              patch fragment with 8 two-byte LDS reads.  Output channels are permuted inside the
+//              MFMA rows so that every lane ends up with a contiguous run of channels.
+//   thin_out   wide Cin -> Cout <= 16: a wave walks down a 16-pixel-wide strip; every input row
+//              is loaded once (16 bytes per lane, straight into the B fragment) and feeds the K
+//              output rows it belongs to, whose accumulators rotate through registers.
+//   thin_wgrad weight gradient with one 64-channel side: the contraction runs over pixels, so
+//              the wide operand is staged in LDS (global_load_lds, XOR-swizzled rows) and read
+//              with the transposing ds_read_b64_tr_b16; block partial sums go to a slab that a
+//              second kernel adds up in a fixed order.
+#include "conv_shapes.h"
+
+namespace vamd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+static __device__ __attribute__((aligned(256))) unsigned char t_zero_page[256];
+
+#define TGPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define TLPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ bf16x8_t zero8() {
+    bf16x8_t z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+    return z;
+}
+
+// ---------------------------------------------------------------------------------- thin_in
+// Block = one 16x16 pixel tile of one image, 4 waves x 4 tile rows.  Cout = 16 * NTN.
+template <int K, int NTN>
+__global__ void __launch_bounds__(256)
+thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                    const float* __restrict__ bias, const float* __restrict__ temb,
+                    const bf16_t* __restrict__ res, const bf16_t* __restrict__ res2, bf16_t* __restrict__ y,
+                    int tiles_w, int tiles_h) {
+    constexpr int HT = 16 + K - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);          // [HT][HT][Cin], zero outside the image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_w;
+    bid /= tiles_w;
+    const int ty = bid % tiles_h;
+    const int b = bid / tiles_h;
+    const int h0 = ty * 16, w0 = tx * 16;
+    const int Cin = g.Cin, Ktot = K * K * Cin, Cout = 16 * NTN;
+
+    const int total = HT * HT * Cin;
+    for (int e = tid; e < total; e += 256) {
+        const int c = e % Cin, pp = e / Cin;
+        const int xx = pp % HT, yy = pp / HT;
+        const int hi = h0 + yy - g.pad, wi = w0 + xx - g.pad;
+        bf16_t v = (bf16_t)0.f;
+        if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+            v = x[(((int64_t)b * g.H + hi) * g.W + wi) * Cin + c];
+        halo[e] = v;
+    }
+
+    // A = filter, rows permuted: MFMA jt, row i  <->  output channel (i>>2)*(4*NTN) + 4*jt + (i&3),
+    // so that the 4*NTN accumulators of a lane are consecutive channels
+    const int p = lane & 15, grp = lane >> 4;
+    bf16x8_t afrag[NTN];
+    int off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * grp + j;
+        if (k < Ktot) {
+            const int tap = k / Cin, c = k - tap * Cin;
+            const int r = tap / K, s = tap - r * K;
+            off[j] = (r * HT + s) * Cin + c;
+        } else {
+            off[j] = 0;                       // any finite element: its filter entry is zero
+        }
+#pragma unroll
+        for (int jt = 0; jt < NTN; ++jt) {
+            const int co = (p >> 2) * (4 * NTN) + 4 * jt + (p & 3);
+            afrag[jt][j] = k < Ktot ? w[(int64_t)co * Ktot + k] : (bf16_t)0.f;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+        const int tyy = wave * 4 + rr;
+        const int h = h0 + tyy;
+        if (h >= g.H) break;                  // wave-uniform
+        const int base = (tyy * HT + p) * Cin;
+        bf16x8_t bfrag;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bfrag[j] = halo[base + off[j]];
+        f32x4_t acc[NTN];
+#pragma unroll
+        for (int jt = 0; jt < NTN; ++jt)
+            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[jt], bfrag, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const int wq = w0 + p;
+        if (wq < g.W) {
+            const int64_t m = ((int64_t)b * g.H + h) * g.W + wq;
+            const int c0 = grp * 4 * NTN;
+#pragma unroll
+            for (int ch = 0; ch < NTN / 2; ++ch) {            // chunks of 8 channels = 16 bytes
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[ch * 2 + (e >> 2)][e & 3];
+                const int cc = c0 + ch * 8;
+                if (bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bias[cc + e];
+                }
+                if (temb) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += temb[(int64_t)b * Cout + cc + e];
+                }
+                if (res) {
+                    const Vec16<bf16_t> rv = *reinterpret_cast<const Vec16<bf16_t>*>(res + m * Cout + cc);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += to_f(rv.v[e]);
+                }
+                if (res2) {
+                    const Vec16<bf16_t> rv = *reinterpret_cast<const Vec16<bf16_t>*>(res2 + m * Cout + cc);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += to_f(rv.v[e]);
+                }
+                Vec16<bf16_t> ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov.v[e] = from_f<bf16_t>(v[e]);
+                *reinterpret_cast<Vec16<bf16_t>*>(y + m * Cout + cc) = ov;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------- thin_out
+// Wave = one strip of 16 pixels x R rows of one image.  Cin = 32 * NH, Cout <= 16.
+template <int K, int NH>
+__global__ void __launch_bounds__(256)
+thin_out_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                     const float* __restrict__ bias, const float* __restrict__ temb,
+                     const bf16_t* __restrict__ res, const bf16_t* __restrict__ res2, bf16_t* __restrict__ y,
+                     int strips_w, int strips_h, int R, int ntasks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int task = blockIdx.x * 4 + wave;
+    if (task >= ntasks) return;                               // no barriers in this kernel
+    const int sx = task % strips_w;
+    task /= strips_w;
+    const int sy = task % strips_h;
+    const int b = task / strips_h;
+    const int w0 = sx * 16, h0 = sy * R;
+    const int h1 = h0 + R < g.H ? h0 + R : g.H;
+    const int p = lane & 15, grp = lane >> 4;
+    const int Cin = 32 * NH;
+
+    // A = filter: row i = output channel, k = 8 channels of one tap
+    bf16x8_t wf[K * K][NH];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf)
+            wf[t][hf] = p < g.Cout ? *reinterpret_cast<const bf16x8_t*>(w + ((int64_t)p * K * K + t) * Cin + hf * 32 + grp * 8)
+                                   : zero8();
+
+    // B = input: column = pixel w0 + p (shifted by the tap), k = the same 8 channels
+    auto load_row = [&](int hi, bf16x8_t (&f)[K][NH]) {
+        const bool hok = (unsigned)hi < (unsigned)g.H;
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const int wi = w0 + p + s - g.pad;
+            const bool ok = hok && (unsigned)wi < (unsigned)g.W;
+            const bf16_t* src = x + (((int64_t)b * g.H + hi) * g.W + wi) * Cin + grp * 8;
+#pragma unroll
+            for (int hf = 0; hf < NH; ++hf)
+                f[s][hf] = ok ? *reinterpret_cast<const bf16x8_t*>(src + hf * 32) : zero8();
+        }
+    };
+
+    f32x4_t acc[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int hi_first = h0 - g.pad, hi_last = h1 - 1 + (K - 1 - g.pad);
+    bf16x8_t cur[K][NH], nxt[K][NH];
+    load_row(hi_first, cur);
+#pragma unroll 1
+    for (int hi = hi_first; hi <= hi_last; ++hi) {
+        if (hi < hi_last) load_row(hi + 1, nxt);
+        // input row hi feeds output row hi + pad - r through filter row r; slot i = K-1-r holds
+        // output row hi + pad - (K-1) + i
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+            for (int s = 0; s < K; ++s)
+#pragma unroll
+                for (int hf = 0; hf < NH; ++hf)
+                    acc[K - 1 - r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r * K + s][hf], cur[s][hf], acc[K - 1 - r], 0, 0, 0);
+        const int hout = hi + g.pad - (K - 1);                 // slot 0 is complete
+        const int wq = w0 + p;
+        if (hout >= h0 && hout < h1 && wq < g.W) {
+            const int64_t m = ((int64_t)b * g.H + hout) * g.W + wq;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * grp + r;                    // D row = output channel
+                if (co < g.Cout) {
+                    float v = acc[0][r];
+                    if (bias) v += bias[co];
+                    if (temb) v += temb[(int64_t)b * g.Cout + co];
+                    if (res) v += to_f(res[m * g.Cout + co]);
+                    if (res2) v += to_f(res2[m * g.Cout + co]);
+                    y[m * g.Cout + co] = from_f<bf16_t>(v);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i + 1 < K; ++i) acc[i] = acc[i + 1];
+        acc[K - 1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < K; ++s)
+#pragma unroll
+            for (int hf = 0; hf < NH; ++hf) cur[s][hf] = nxt[s][hf];
+    }
+}
+
+// ------------------------------------------------------------------------------- thin_wgrad
+// Rows of 64 bf16 channels (128 bytes) in LDS, read with ds_read_b64_tr_b16: 32 lanes read 8 rows
+// x 32 bytes.  Swizzling the 32-byte unit of a row by (row bit 1, row bit 3) spreads any 8 rows
+// {a..a+3, a+8..a+11} over the 8 bank groups.
+__device__ __forceinline__ int sw128(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+__device__ __forceinline__ bf16x4_t tr_read(const unsigned char* base, int row, int col) {
+    const int piece = (col >> 3) ^ (sw128(row) << 1);
+    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(base + row * 128 + piece * 16 + (col & 7) * 2));
+    return __builtin_bit_cast(bf16x4_t, v);
+}
+
+// dW[n][f] (n < 64 output channels, f = (tap, c) < 32) from dY [pixels][64] and X [pixels][Cin<=4].
+// Block walks 16x16 pixel tiles; wave w contracts pixels 64w..64w+63 of each tile for all channels.
+template <int K>
+__global__ void __launch_bounds__(256)
+thin_wgrad_wideout_kernel(ConvGeom g, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                          float* __restrict__ slab, int tiles_w, int tiles_h, int ntiles) {
+    constexpr int HT = 16 + K - 1;
+    constexpr int DYT = 256 * 128;                            // dY tile bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* dyt = smem_raw;
+    bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw + DYT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Cin = g.Cin, Ktot = K * K * Cin;
+    const int j16 = lane & 15, grp = lane >> 4;
+
+    int off[2];
+    bool fok[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const int f = jt * 16 + j16;
+        fok[jt] = f < Ktot;
+        const int ff = fok[jt] ? f : 0;
+        const int tap = ff / Cin, c = ff - tap * Cin;
+        const int r = tap / K, s = tap - r * K;
+        off[jt] = (r * HT + s) * Cin + c;
+    }
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) acc[nt][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int srow = tid >> 3, slot = tid & 7;
+    const int piece = slot ^ (sw128(srow) << 1);              // rows srow + 32*i share the swizzle
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int q = t;
+        const int tx = q % tiles_w;
+        q /= tiles_w;
+        const int ty = q % tiles_h;
+        const int b = q / tiles_h;
+        const int h0 = ty * 16, w0 = tx * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = i * 32 + srow;                      // tile pixel
+            const int h = h0 + (k >> 4), wq = w0 + (k & 15);
+            const bool ok = h < g.H && wq < g.W;
+            const bf16_t* src = ok ? dy + (((int64_t)b * g.H + h) * g.W + wq) * 64 + piece * 8
+                                   : reinterpret_cast<const bf16_t*>(t_zero_page);
+            __builtin_amdgcn_global_load_lds(TGPTR(src), TLPTR(dyt + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+        const int total = HT * HT * Cin;
+        for (int e = tid; e < total; e += 256) {
+            const int c = e % Cin, pp = e / Cin;
+            const int xx = pp % HT, yy = pp / HT;
+            const int hi = h0 + yy - g.pad, wi = w0 + xx - g.pad;
+            bf16_t v = (bf16_t)0.f;
+            if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+                v = x[(((int64_t)b * g.H + hi) * g.W + wi) * Cin + c];
+            halo[e] = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k0 = wave * 64 + ks * 32;
+            // B = patches: column f, k = pixels k0 + 8*grp .. +7 (one tile row, 8 consecutive x)
+            const int hb = (((k0 >> 4) + (grp >> 1)) * HT + 8 * (grp & 1)) * Cin;
+            bf16x8_t bfr[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const bf16_t v = halo[hb + off[jt] + jj * Cin];
+                    bfr[jt][jj] = fok[jt] ? v : (bf16_t)0.f;
+                }
+            // A = dY transposed: row n, k = the same pixels
+            const int rq = k0 + 8 * grp + (j16 >> 2);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = nt * 16 + 4 * (lane & 3);
+                const bf16x4_t lo = tr_read(dyt, rq, col), hi4 = tr_read(dyt, rq + 4, col);
+                bf16x8_t a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = lo[e]; a[4 + e] = hi4[e]; }
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+                    acc[nt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[jt], acc[nt][jt], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                      // tile consumed before it is overwritten
+    }
+
+    // sum the 4 waves' partial products in LDS, then one slab row per block: [n][Ktot]
+    float* red = reinterpret_cast<float*>(smem_raw);          // [wave][8][64][4]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+            *reinterpret_cast<f32x4_t*>(red + ((wave * 8 + nt * 2 + jt) * 64 + lane) * 4) = acc[nt][jt];
+    __syncthreads();
+    float* out = slab + (int64_t)blockIdx.x * 64 * Ktot;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = i * 256 + tid;                          // (idx8, lane', r)
+        const float v = (red[e] + red[2048 + e]) + (red[4096 + e] + red[6144 + e]);
+        const int r = e & 3, l = (e >> 2) & 63, idx = e >> 8;
+        const int n = (idx >> 1) * 16 + 4 * (l >> 4) + r, f = (idx & 1) * 16 + (l & 15);
+        if (f < Ktot) out[n * Ktot + f] = v;
+    }
+}
+
+// dW[n][tap][c] (n <= 4 output channels, c < 64) from dY [pixels][Cout<=4] and X [pixels][64].
+// Wave w owns input channels 16w..16w+15 and all taps; the X window of a tile sits in LDS.
+template <int K>
+__global__ void __launch_bounds__(256)
+thin_wgrad_widein_kernel(ConvGeom g, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                         float* __restrict__ slab, int tiles_w, int tiles_h, int ntiles) {
+    constexpr int HT = 16 + K - 1;
+    constexpr int NPASS = (HT * HT * 8 + 255) / 256;
+    constexpr int XT = NPASS * 256 * 16;                      // X window bytes (whole passes)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* xt = smem_raw;
+    bf16_t* dyt = reinterpret_cast<bf16_t*>(smem_raw + XT);   // [256 pixels][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j16 = lane & 15, grp = lane >> 4;
+
+    f32x4_t acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int q = t;
+        const int tx = q % tiles_w;
+        q /= tiles_w;
+        const int ty = q % tiles_h;
+        const int b = q / tiles_h;
+        const int h0 = ty * 16, w0 = tx * 16;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int pi = i * 256 + tid;
+            const int hp = pi >> 3, slot = pi & 7;            // window pixel, physical piece
+            const int piece = slot ^ (sw128(hp) << 1);
+            const int yy = hp / HT, xx = hp - yy * HT;
+            const int hi = h0 + yy - g.pad, wi = w0 + xx - g.pad;
+            const bool ok = hp < HT * HT && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+            const bf16_t* src = ok ? x + (((int64_t)b * g.H + hi) * g.W + wi) * 64 + piece * 8
+                                   : reinterpret_cast<const bf16_t*>(t_zero_page);
+            __builtin_amdgcn_global_load_lds(TGPTR(src), TLPTR(xt + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+        {
+            const int h = h0 + (tid >> 4), wq = w0 + (tid & 15);
+            const bool ok = h < g.H && wq < g.W;
+            const bf16_t* src = dy + (((int64_t)b * g.H + h) * g.W + wq) * g.Cout;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) dyt[tid * 4 + n] = (ok && n < g.Cout) ? src[n] : (bf16_t)0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll 1
+        for (int ks = 0; ks < 8; ++ks) {
+            const int k0 = ks * 32;
+            // B = dY: column n (lanes with n >= 4 carry zeros), k = pixels k0 + 8*grp .. +7
+            bf16x8_t bfr;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const bf16_t v = dyt[(k0 + 8 * grp + jj) * 4 + (j16 & 3)];
+                bfr[jj] = j16 < 4 ? v : (bf16_t)0.f;
+            }
+            const int ky = (k0 >> 4) + (grp >> 1), kx = 8 * (grp & 1) + (j16 >> 2);
+            const int col = wave * 16 + 4 * (lane & 3);
+#pragma unroll
+            for (int r = 0; r < K; ++r)
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    const int hp = (ky + r) * HT + kx + s;     // window row of pixel (ky, kx) under tap (r, s)
+                    const bf16x4_t lo = tr_read(xt, hp, col), hi4 = tr_read(xt, hp + 4, col);
+                    bf16x8_t a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] = lo[e]; a[4 + e] = hi4[e]; }
+                    acc[r * K + s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr, acc[r * K + s], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    // D row = channel 16w + 4*grp + r, column = n; slab row per block laid out like dW [n][tap][c]
+    if (j16 < g.Cout) {
+        float* out = slab + (int64_t)blockIdx.x * g.Cout * K * K * 64;
+#pragma unroll
+        for (int t = 0; t < K * K; ++t)
+            *reinterpret_cast<f32x4_t*>(out + ((int64_t)j16 * K * K + t) * 64 + wave * 16 + 4 * grp) = acc[t];
+    }
+}
+
+// dw[i] = sum over blocks of slab[block][i], blocks added in a fixed order
+__global__ void __launch_bounds__(256)
+slab_sum_kernel(const float* __restrict__ slab, int nblocks, int total, float* __restrict__ dw) {
+    __shared__ float red[8][32];
+    const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
+    float sum = 0.f;
+    if (idx < total)
+        for (int b = q; b < nblocks; b += 8) sum += slab[(int64_t)b * total + idx];
+    red[q][e] = sum;
+    __syncthreads();
+    if (q == 0 && idx < total)
+        dw[idx] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+}
+
+// ------------------------------------------------------------------------------------ host
+template <typename Kern> static int lds_limit(Kern kernel, size_t bytes, const char* who) {
+    if (bytes <= 64 * 1024) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute(%zu) failed: %s", who, bytes, hipGetErrorString(e));
+    return 0;
+}
+
+bool thin_in_mfma_ok(const ConvGeom& g) {
+    return g.stride == 1 && !g.up && (g.k == 1 || g.k == 3) && g.Cin <= 4 && g.k * g.k * g.Cin <= 32 &&
+           (g.Cout == 32 || g.Cout == 64 || g.Cout == 128);
+}
+
+template <int K, int NTN>
+static void launch_thin_in(const ConvGeom& g, const void* x, const void* w, const float* bias, const float* temb,
+                           const void* res, const void* res2, void* y, hipStream_t st) {
+    const int tw = (g.W + 15) / 16, th = (g.H + 15) / 16;
+    constexpr int HT = 16 + K - 1;
+    const size_t lds = (size_t)HT * HT * g.Cin * 2;
+    hipLaunchKernelGGL((thin_in_mfma_kernel<K, NTN>), dim3((unsigned)(g.B * th * tw)), dim3(256), lds, st, g,
+                       (const bf16_t*)x, (const bf16_t*)w, bias, temb, (const bf16_t*)res, (const bf16_t*)res2,
+                       (bf16_t*)y, tw, th);
+}
+
+int thin_in_mfma(const ConvGeom& g, const void* x, const void* w, const float* bias, const float* temb,
+                 const void* res, const void* res2, void* y, hipStream_t st) {
+    const int ntn = g.Cout / 16;
+    if (g.k == 3) {
+        if (ntn == 2) launch_thin_in<3, 2>(g, x, w, bias, temb, res, res2, y, st);
+        else if (ntn == 4) launch_thin_in<3, 4>(g, x, w, bias, temb, res, res2, y, st);
+        else launch_thin_in<3, 8>(g, x, w, bias, temb, res, res2, y, st);
+    } else {
+        if (ntn == 2) launch_thin_in<1, 2>(g, x, w, bias, temb, res, res2, y, st);
+        else if (ntn == 4) launch_thin_in<1, 4>(g, x, w, bias, temb, res, res2, y, st);
+        else launch_thin_in<1, 8>(g, x, w, bias, temb, res, res2, y, st);
+    }
+    VAMD_LAUNCH_OK("thin_in_mfma");
+    return 0;
+}
+
+bool thin_out_mfma_ok(const ConvGeom& g) {
+    if (g.stride != 1 || g.up || g.Cout > 16) return false;
+    if (g.k == 3) return g.Cin == 32 || g.Cin == 64;
+    if (g.k == 1) return g.Cin == 32 || g.Cin == 64 || g.Cin == 128;
+    return false;
+}
+
+template <int K, int NH>
+static void launch_thin_out(const ConvGeom& g, const void* x, const void* w, const float* bias, const float* temb,
+                            const void* res, const void* res2, void* y, hipStream_t st) {
+    const int R = 32;
+    const int sw = (g.W + 15) / 16, sh = (g.H + R - 1) / R;
+    const int ntasks = g.B * sw * sh;
+    hipLaunchKernelGGL((thin_out_mfma_kernel<K, NH>), dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, st, g,
+                       (const bf16_t*)x, (const bf16_t*)w, bias, temb, (const bf16_t*)res, (const bf16_t*)res2,
+                       (bf16_t*)y, sw, sh, R, ntasks);
+}
+
+int thin_out_mfma(const ConvGeom& g, const void* x, const void* w, const float* bias, const float* temb,
+                  const void* res, const void* res2, void* y, hipStream_t st) {
+    const int nh = g.Cin / 32;
+    if (g.k == 3) {
+        if (nh == 1) launch_thin_out<3, 1>(g, x, w, bias, temb, res, res2, y, st);
+        else launch_thin_out<3, 2>(g, x, w, bias, temb, res, res2, y, st);
+    } else {
+        if (nh == 1) launch_thin_out<1, 1>(g, x, w, bias, temb, res, res2, y, st);
+        else if (nh == 2) launch_thin_out<1, 2>(g, x, w, bias, temb, res, res2, y, st);
+        else launch_thin_out<1, 4>(g, x, w, bias, temb, res, res2, y, st);
+    }
+    VAMD_LAUNCH_OK("thin_out_mfma");
+    return 0;
+}
+
+bool thin_wgrad_mfma_ok(const ConvGeom& g) {
+    if (g.stride != 1 || g.up || !(g.k == 1 || g.k == 3)) return false;
+    if (g.Cin <= 4 && g.Cout == 64) return g.k * g.k * g.Cin <= 32;
+    return g.Cin == 64 && g.Cout <= 4;
+}
+
+static int thin_wgrad_mfma_blocks(const ConvGeom& g) {
+    const int ntiles = g.B * ((g.H + 15) / 16) * ((g.W + 15) / 16);
+    return ntiles < 512 ? ntiles : 512;
+}
+
+size_t thin_wgrad_mfma_workspace(const ConvGeom& g) {
+    return (size_t)thin_wgrad_mfma_blocks(g) * g.Cout * g.k * g.k * g.Cin * sizeof(float);
+}
+
+int thin_wgrad_mfma(const ConvGeom& g, const void* dy, const void* x, float* dw, void* workspace, hipStream_t st) {
+    const int tw = (g.W + 15) / 16, th = (g.H + 15) / 16;
+    const int ntiles = g.B * th * tw;
+    const int nb = thin_wgrad_mfma_blocks(g);
+    float* slab = reinterpret_cast<float*>(workspace);
+    const int total = g.Cout * g.k * g.k * g.Cin;
+    const int HT = 16 + g.k - 1;
+    if (g.Cout == 64) {
+        const size_t lds = 256 * 128 + (size_t)HT * HT * g.Cin * 2;
+        if (g.k == 3)
+            hipLaunchKernelGGL((thin_wgrad_wideout_kernel<3>), dim3(nb), dim3(256), lds, st, g, (const bf16_t*)dy,
+                               (const bf16_t*)x, slab, tw, th, ntiles);
+        else
+            hipLaunchKernelGGL((thin_wgrad_wideout_kernel<1>), dim3(nb), dim3(256), lds, st, g, (const bf16_t*)dy,
+                               (const bf16_t*)x, slab, tw, th, ntiles);
+    } else {
+        const int npass = (HT * HT * 8 + 255) / 256;
+        const size_t lds = (size_t)npass * 256 * 16 + 256 * 4 * 2;
+        if (g.k == 3)
+            hipLaunchKernelGGL((thin_wgrad_widein_kernel<3>), dim3(nb), dim3(256), lds, st, g, (const bf16_t*)dy,
+                               (const bf16_t*)x, slab, tw, th, ntiles);
+        else
+            hipLaunchKernelGGL((thin_wgrad_widein_kernel<1>), dim3(nb), dim3(256), lds, st, g, (const bf16_t*)dy,
+                               (const bf16_t*)x, slab, tw, th, ntiles);
+    }
+    VAMD_LAUNCH_OK("thin_wgrad_mfma");
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((total + 31) / 32), dim3(256), 0, st, slab, nb, total, dw);
+    VAMD_LAUNCH_OK("slab_sum");
+    return 0;
+}
+
+}  // namespace vamd

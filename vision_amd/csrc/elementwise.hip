@@ -238,35 +238,51 @@ __global__ void timeembed_kernel(const float* __restrict__ t, const float* __res
     emb[b * dim + half + j] = cosf(a);
 }
 
-// thread per (b, o)
-__global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                  const float* __restrict__ bias, float* __restrict__ y, int B,
-                                  int I, int O, int act_in, float slope) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * O) return;
+// wave per (b, o): lanes split the input features, coalesced reads of both rows
+__global__ void __launch_bounds__(256)
+linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                  const float* __restrict__ bias, float* __restrict__ y, int B,
+                  int I, int O, int act_in, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= B * O) return;                                 // wave-uniform
     const int b = idx / O, o = idx - b * O;
     const float* xr = x + (int64_t)b * I;
     const float* wr = W + (int64_t)o * I;
     float acc = 0.f;
-    for (int i = 0; i < I; ++i) {
+    for (int i = lane; i < I; i += 64) {
         float v = xr[i];
         if (act_in) v = leaky(v, slope);
         acc = fmaf(v, wr[i], acc);
     }
-    y[idx] = acc + (bias ? bias[o] : 0.f);
+    acc = wave_sum(acc);
+    if (lane == 0) y[idx] = acc + (bias ? bias[o] : 0.f);
 }
 
-// thread per (b, i): dx[b][i] = act'(x) * sum_o dy[b][o] W[o][i]
-__global__ void linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                     const float* __restrict__ dy, float* __restrict__ dx, int B,
-                                     int I, int O, int act_in, float slope, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * I) return;
-    const int b = idx / I, i = idx - b * I;
+// block per (b, 16 inputs): 16 slices of the output features are reduced through LDS.
+// dx[b][i] = act'(x) * sum_o dy[b][o] W[o][i]
+__global__ void __launch_bounds__(256)
+linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                     const float* __restrict__ dy, float* __restrict__ dx, int B,
+                     int I, int O, int act_in, float slope, int accumulate) {
+    __shared__ float red[16][17];
+    const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int chunks = (I + 15) / 16;
+    const int b = blockIdx.x / chunks, i = (blockIdx.x - b * chunks) * 16 + il;
     float acc = 0.f;
-    for (int o = 0; o < O; ++o) acc = fmaf(dy[(int64_t)b * O + o], W[(int64_t)o * I + i], acc);
-    if (act_in && !(x[idx] > 0.f)) acc *= slope;
-    dx[idx] = accumulate ? dx[idx] + acc : acc;
+    if (i < I) {
+#pragma unroll 4
+        for (int o = sl; o < O; o += 16) acc = fmaf(dy[(int64_t)b * O + o], W[(int64_t)o * I + i], acc);
+    }
+    red[sl][il] = acc;
+    __syncthreads();
+    if (sl != 0 || i >= I) return;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][il];
+    const int64_t idx = (int64_t)b * I + i;
+    if (act_in && !(x[idx] > 0.f)) v *= slope;
+    dx[idx] = accumulate ? dx[idx] + v : v;
 }
 
 // thread per (o, i): dW[o][i] = sum_b dy[b][o] act(x[b][i]); i == 0 also writes dbias[o]
@@ -518,7 +534,7 @@ int vamd_linear_fwd(const float* x, const float* W, const float* bias, float* y,
                     int O, int act_in, float slope, void* stream) {
     VAMD_REQUIRE(x && W && y && B > 0 && I > 0 && O > 0, "vamd_linear_fwd: bad argument");
     const int total = B * O;
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((total + 3) / 4), dim3(256), 0, as_stream(stream),
                        x, W, bias, y, B, I, O, act_in, slope);
     VAMD_LAUNCH_OK("vamd_linear_fwd");
     return 0;
@@ -529,8 +545,8 @@ int vamd_linear_bwd(const float* x, const float* W, const float* dy, float* dx, 
                     void* stream) {
     VAMD_REQUIRE(x && W && dy && dW && B > 0 && I > 0 && O > 0, "vamd_linear_bwd: bad argument");
     if (dx) {
-        const int total = B * I;
-        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((total + 255) / 256), dim3(256), 0,
+        const int total = B * ((I + 15) / 16);
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(total), dim3(256), 0,
                            as_stream(stream), x, W, dy, dx, B, I, O, act_in, slope, accumulate_dx);
     }
     const int total = O * I;

@@ -243,21 +243,26 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ partial, int nchunk
     }
 }
 
-// one wave per channel: per_g0[g][c] = sum over chunks of component 0, total0/1[c] = sums over g too
-__global__ void sum_over_g_kernel(const float* __restrict__ partial, int nchunk, int G, int C,
-                                  float* per_g0, float* total0, float* total1) {
-    const int c = blockIdx.x;
+// one block of 4 waves per channel: per_g0[g][c] = sum over chunks of component 0 (wave w takes
+// g = w, w+4, ...), total0/1[c] = sums over g too, combined in a fixed order
+__global__ void __launch_bounds__(256)
+sum_over_g_kernel(const float* __restrict__ partial, int nchunk, int G, int C,
+                  float* per_g0, float* total0, float* total1) {
+    __shared__ double red[4][2];
+    const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double t0 = 0.0, t1 = 0.0;
-    for (int g = 0; g < G; ++g) {
+    for (int g = wave; g < G; g += 4) {
         double s0, s1;
         reduce_parts(partial + (int64_t)g * nchunk * C * 2, nchunk, C, c, s0, s1);
-        if (per_g0 && threadIdx.x == 0) per_g0[(int64_t)g * C + c] = (float)s0;
+        if (per_g0 && lane == 0) per_g0[(int64_t)g * C + c] = (float)s0;
         t0 += s0;
         t1 += s1;
     }
+    if (lane == 0) { red[wave][0] = t0; red[wave][1] = t1; }
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    if (total0) total0[c] = (float)t0;
-    if (total1) total1[c] = (float)t1;
+    if (total0) total0[c] = (float)((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
+    if (total1) total1[c] = (float)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
 }
 
 template <typename T, int VEC>
@@ -466,7 +471,7 @@ int vamd_gn_bwd_finalize(const float* partial, int nchunk, int B, int C, int gro
     const int total = B * groups;
     hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((total + 63) / 64), dim3(64), 0, as_stream(stream),
                        partial, nchunk, B, C, groups, (double)HW * (C / groups), gamma, rstd, cA, cB, cC);
-    hipLaunchKernelGGL(sum_over_g_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial,
+    hipLaunchKernelGGL(sum_over_g_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial,
                        nchunk, B, C, (float*)nullptr, dbeta, dgamma);
     VAMD_LAUNCH_OK("vamd_gn_bwd_finalize");
     return 0;
@@ -502,7 +507,7 @@ int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const f
 int vamd_sum_finalize(const float* partial, int nchunk, int G, int C, float* per_g, float* total,
                       void* stream) {
     VAMD_REQUIRE(partial && nchunk > 0 && G > 0 && C > 0 && (per_g || total), "vamd_sum_finalize: bad argument");
-    hipLaunchKernelGGL(sum_over_g_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial,
+    hipLaunchKernelGGL(sum_over_g_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial,
                        nchunk, G, C, per_g, total, (float*)nullptr);
     VAMD_LAUNCH_OK("vamd_sum_finalize");
     return 0;
