@@ -49,12 +49,11 @@ struct Gather {
     int He, We;            // valid range of the tap coordinate u = ho*stride + r - pad
     int Ho, Wo;            // extents that m enumerates
     int k, stride, pad;
-    int shift;             // 1: stored row = u >> 1 (nearest upsample or zero insertion)
-    int parity;            // 1: only even u, v carry data (zero insertion: dgrad of stride 2)
+    int shift;             // 1: stored row = u >> 1 (nearest 2x upsample folded into the gather)
     int M, Ktot;           // rows, and (tap rows)*(tap columns)*Cin
     FastDiv div_howo, div_wo;
     // Sub-filter views (stride-2 input gradient, one launch per output parity class):
-    int ks;                // tap columns (k for a square filter); tap rows = Ktot / (ks * Cin)
+    int kr, ks;            // tap rows and columns (k, k for a square filter); Ktot = kr * ks * Cin
     int wr0, ws0, wstep, wk;   // tap (tr, ts) reads filter tap (wr0 + wstep*tr, ws0 + wstep*ts) of a wk x wk filter
     int oH, oW, ostep, oph, opw;   // ostep = 2: row (b, ho, wo) is written to pixel (b, 2*ho + oph, 2*wo + opw) of an oH x oW image
 };
@@ -68,9 +67,16 @@ struct Epilogue {
     int out_f32;           // store fp32 instead of T
 };
 
+// Branch-free pointer select: keeps the staging code of a K-step in one basic block, so that the
+// scheduler may place it between MFMAs.
+template <typename T> __device__ __forceinline__ const T* pick_ptr(bool ok, const T* a, const T* b) {
+    const uint64_t m = 0ull - (uint64_t)ok;
+    return reinterpret_cast<const T*>(((uint64_t)a & m) | ((uint64_t)b & ~m));
+}
+
 template <typename T> struct ElemTraits;
-template <> struct ElemTraits<bf16_t> { static constexpr int PIECE = 8; };   // elements per 16 bytes
-template <> struct ElemTraits<float> { static constexpr int PIECE = 4; };
+template <> struct ElemTraits<bf16_t> { static constexpr int PIECE = 8; typedef bf16x8_t Frag; };   // elements per 16 bytes
+template <> struct ElemTraits<float> { static constexpr int PIECE = 4; typedef f32x4_t Frag; };
 
 constexpr int kBM = 128;
 constexpr int kRowBytes = 128;                   // reduction bytes per K-step
@@ -81,7 +87,7 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <typename T, int BN>
+template <typename T, int BN, bool UP>
 __global__ void __launch_bounds__(256, 2)
 conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
                     Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, int64_t strideA,
@@ -104,56 +110,87 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
     x += (int64_t)blockIdx.z * strideA;
     w += (int64_t)blockIdx.z * strideB;
 
-    // ---- staging state: this thread copies piece `slot` of rows srow + 32*i
+    // ---- staging state: this thread copies piece `slot` of rows srow + 32*i.
+    // Per row: the element offset of its window origin and one validity bit per filter tap, so a
+    // K-step costs an add, a bit test and a select per row (the tensors are < 2 GiB: 32-bit offsets).
     const int srow = tid >> 3, slot = tid & 7;
     const int chunk = slot ^ (srow & 7);                 // logical piece held by this LDS slot
-    int a_ho[4], a_wo[4];
-    int64_t a_pix[4];
-    bool a_ok[4];
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    int a_base[4], a_h0[4], a_w0[4];
+    uint32_t a_mask[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t m = m0 + srow + 32 * i;
-        a_ok[i] = m < (uint32_t)gp.M;
+        const bool row_ok = m < (uint32_t)gp.M;
         const uint32_t b = fdiv(m, gp.div_howo);
         const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
         const uint32_t ho = fdiv(rem, gp.div_wo);
-        a_ho[i] = (int)ho * gp.stride - gp.pad;
-        a_wo[i] = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad;
-        a_pix[i] = (int64_t)b * gp.Hin * gp.Win;
+        const int h0 = (int)ho * gp.stride - gp.pad;
+        const int w0 = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad;
+        a_h0[i] = h0;
+        a_w0[i] = w0;
+        a_base[i] = UP ? (int)b * gp.Hin * gp.Win * gp.ldx : (((int)b * gp.Hin + h0) * gp.Win + w0) * gp.ldx;
+        uint32_t mask = 0, bit = 1;
+        for (int r = 0; r < gp.kr; ++r) {
+            const bool rok = row_ok && (unsigned)(h0 + r) < (unsigned)gp.He;
+            for (int q = 0; q < gp.ks; ++q, bit <<= 1)
+                if (rok && (unsigned)(w0 + q) < (unsigned)gp.We) mask |= bit;
+        }
+        a_mask[i] = mask;
+    }
+    const T* b_ptr[BN / 32];
+    bool b_ok[BN / 32];
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+        const int n = n0 + srow + 32 * i;
+        b_ok[i] = n < N;
+        b_ptr[i] = w + (int64_t)(b_ok[i] ? n : 0) * ldw;
     }
     int f = chunk * PIECE;                               // flattened (tap, c) index of my piece
-    int c = f, tr = 0, ts = 0;
+    int c = f, tr = 0, ts = 0, tap = 0;
+    auto advance = [&]() {                               // branch-free: at most two taps per K-step
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
-        if (c >= gp.Cin) { c -= gp.Cin; if (++ts == gp.ks) { ts = 0; ++tr; } }
+        for (int it = 0; it < 2; ++it) {
+            const int adv = c >= gp.Cin ? 1 : 0;
+            c -= adv ? gp.Cin : 0;
+            tap += adv;
+            ts += adv;
+            const int wrap = ts == gp.ks ? 1 : 0;
+            ts = wrap ? 0 : ts;
+            tr += wrap;
+        }
+    };
+    advance();
 
-    auto stage = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE;
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+    // One K-step of staging is issued in two halves (activation rows, filter rows) so that each can
+    // sit between the fragment reads and the MFMAs of the K-step being computed.
+    auto stage_a = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE + wave_s * 1024;
         const bool f_ok = f < gp.Ktot;
+        const int tapoff = (tr * gp.Win + ts) * gp.ldx + c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int u = a_ho[i] + tr, v = a_wo[i] + ts;
-            bool ok = a_ok[i] && f_ok && (unsigned)u < (unsigned)gp.He && (unsigned)v < (unsigned)gp.We;
-            if (gp.parity) ok = ok && (((u | v) & 1) == 0);
-            const int hi = u >> gp.shift, wi = v >> gp.shift;
-            const T* src = ok ? x + ((a_pix[i] + (int64_t)hi * gp.Win + wi) * gp.ldx + c)
-                              : reinterpret_cast<const T*>(g_zero_page);
-            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sa + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            const bool ok = f_ok & (bool)((a_mask[i] >> (tap & 31)) & 1u);
+            int off;
+            if constexpr (UP) off = a_base[i] + (((a_h0[i] + tr) >> 1) * gp.Win + ((a_w0[i] + ts) >> 1)) * gp.ldx + c;
+            else off = a_base[i] + tapoff;
+            const T* src = pick_ptr(ok, x + (uint32_t)off, zero);
+            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sa + i * 4096), 16, 0, 0);
         }
-        unsigned char* sb = sa + A_BYTES;
+    };
+    auto stage_b = [&](int buf) {
+        unsigned char* sb = smem + buf * STAGE + A_BYTES + wave_s * 1024;
+        const bool f_ok = f < gp.Ktot;
         const int wf = ((gp.wr0 + gp.wstep * tr) * gp.wk + gp.ws0 + gp.wstep * ts) * gp.Cin + c;   // == f for a plain filter
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i) {
-            const int n = n0 + srow + 32 * i;
-            const bool ok = f_ok && n < N;
-            const T* src = ok ? w + ((int64_t)n * ldw + wf) : reinterpret_cast<const T*>(g_zero_page);
-            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            const T* src = pick_ptr(f_ok & b_ok[i], b_ptr[i] + (uint32_t)wf, zero);
+            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sb + i * 4096), 16, 0, 0);
         }
         f += KSTEP;
         c += KSTEP;
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-            if (c >= gp.Cin) { c -= gp.Cin; if (++ts == gp.ks) { ts = 0; ++tr; } }
+        advance();
     };
 
     f32x4_t acc[4][NT];
@@ -162,51 +199,64 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    using Frag = typename ElemTraits<T>::Frag;           // 16 bytes of one row: 8 bf16 / 4 fp32
     const int frow = lane & 15, fgrp = lane >> 4, fsw = lane & 7;
-    auto compute = [&](int buf) {
+    auto read_frags = [&](int buf, int ks, Frag (&a)[4], Frag (&b)[NT]) {
         const unsigned char* sa = smem + buf * STAGE + (wm * 64 + frow) * kRowBytes;
         const unsigned char* sb = smem + buf * STAGE + A_BYTES + (wn * (BN / 2) + frow) * kRowBytes;
+        const int po = (((ks * 4 + fgrp) ^ fsw) << 4);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int po = (((ks * 4 + fgrp) ^ fsw) << 4);
-            if constexpr (sizeof(T) == 2) {
-                bf16x8_t a[4], b[NT];
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const Frag*>(sa + i * 16 * kRowBytes + po);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 16 * kRowBytes + po);
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const Frag*>(sb + j * 16 * kRowBytes + po);
+    };
+    auto mma = [&](const Frag (&a)[4], const Frag (&b)[NT]) {
+        if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 16 * kRowBytes + po);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            } else {
-                f32x4_t a[4], b[NT];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(sa + i * 16 * kRowBytes + po);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(sb + j * 16 * kRowBytes + po);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
     };
 
     const int nk = (gp.Ktot + KSTEP - 1) / KSTEP;
-    stage(0);
+    stage_a(0);
+    stage_b(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) stage((t + 1) & 1);
-        compute(t & 1);
+    // Steady state, one basic block per K-step: fragment reads of K-step t, then the address
+    // arithmetic and direct-to-LDS loads of K-step t+1 (which cover the LDS latency), then the MFMAs.
+    // LDS reads and LDS-DMA loads keep their program order; everything else floats between MFMAs.
+    for (int t = 0; t + 1 < nk; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        Frag a[4], b[NT];
+        read_frags(cur, 0, a, b);
+        stage_a(nxt);
+        mma(a, b);
+        read_frags(cur, 1, a, b);
+        stage_b(nxt);
+        mma(a, b);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    {
+        const int cur = (nk - 1) & 1;
+        Frag a[4], b[NT];
+        read_frags(cur, 0, a, b);
+        mma(a, b);
+        read_frags(cur, 1, a, b);
+        mma(a, b);
+    }
+    __syncthreads();
 
     // ---- epilogue: accumulators -> fp32 LDS tile -> coalesced 16-byte rows with the fused adds
     float* tile = reinterpret_cast<float*>(smem);
@@ -372,7 +422,6 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
             const int u = (int)ho * gp.stride - gp.pad + b_tr[i];
             const int v = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad + b_ts[i];
             bool ok = m < (uint32_t)gp.M && (unsigned)u < (unsigned)gp.He && (unsigned)v < (unsigned)gp.We;
-            if (gp.parity) ok = ok && (((u | v) & 1) == 0);
             const int hi = u >> gp.shift, wi = v >> gp.shift;
             const T* srcB = ok ? x + ((((int64_t)b * gp.Hin + hi) * gp.Win + wi) * gp.ldx + b_c[i])
                                : reinterpret_cast<const T*>(g_zero_page);
@@ -497,14 +546,14 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 
 // ------------------------------------------------------------------------------------ host side
 static Gather make_gather(int Hin, int Win, int Cin, int He, int We, int Ho, int Wo, int k, int stride,
-                          int pad, int shift, int parity, int64_t M) {
+                          int pad, int shift, int64_t M) {
     Gather g;
     g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.ldx = Cin; g.He = He; g.We = We; g.Ho = Ho; g.Wo = Wo;
-    g.k = k; g.stride = stride; g.pad = pad; g.shift = shift; g.parity = parity;
+    g.k = k; g.stride = stride; g.pad = pad; g.shift = shift;
     g.M = (int)M; g.Ktot = k * k * Cin;
     g.div_howo = make_fastdiv((uint32_t)(Ho * Wo));
     g.div_wo = make_fastdiv((uint32_t)Wo);
-    g.ks = k; g.wr0 = 0; g.ws0 = 0; g.wstep = 1; g.wk = k;
+    g.kr = k; g.ks = k; g.wr0 = 0; g.ws0 = 0; g.wstep = 1; g.wk = k;
     g.oH = 0; g.oW = 0; g.ostep = 0; g.oph = 0; g.opw = 0;
     return g;
 }
@@ -524,7 +573,7 @@ static bool nt_shape_ok(int Cin, int N, int64_t M, int dtype) {
 }
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <typename T, int BN>
+template <typename T, int BN, bool UP>
 static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
                      void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     constexpr int LDS_PIPE = 2 * (kBM * kRowBytes + BN * kRowBytes);
@@ -532,13 +581,13 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
     constexpr int LDS = LDS_PIPE > LDS_EPI ? LDS_PIPE : LDS_EPI;
     static bool configured = false;
     if (!configured) {
-        int rc = set_lds_limit(conv_nt_mfma_kernel<T, BN>, LDS, "conv_nt_mfma");
+        int rc = set_lds_limit(conv_nt_mfma_kernel<T, BN, UP>, LDS, "conv_nt_mfma");
         if (rc) return rc;
         configured = true;
     }
     const int m_tiles = (gp.M + kBM - 1) / kBM, n_tiles = (N + BN - 1) / BN;
     dim3 grid(m_tiles * n_tiles, 1, batch);
-    hipLaunchKernelGGL((conv_nt_mfma_kernel<T, BN>), grid, dim3(256), LDS, st, gp, x, w, N, ldw, ldc, ep, y,
+    hipLaunchKernelGGL((conv_nt_mfma_kernel<T, BN, UP>), grid, dim3(256), LDS, st, gp, x, w, N, ldw, ldc, ep, y,
                        m_tiles, n_tiles, sA, sB, sC);
     VAMD_LAUNCH_OK("conv_nt_mfma");
     return 0;
@@ -547,8 +596,12 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
 template <typename T>
 static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep,
                   void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
-    if (N <= 64) return launch_nt<T, 64>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
-    return launch_nt<T, 128>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+    if (gp.shift) {
+        if (N <= 64) return launch_nt<T, 64, true>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+        return launch_nt<T, 128, true>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+    }
+    if (N <= 64) return launch_nt<T, 64, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+    return launch_nt<T, 128, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
 }
 
 bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype) {
@@ -557,7 +610,7 @@ bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype) {
 
 int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
                   const float* temb, const void* res, const void* res2, void* y, hipStream_t st) {
-    Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, 0, g.M);
+    Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
     Epilogue ep{bias, temb, res, res2, 1.0f, 0};
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
     return run_nt<float>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
@@ -628,9 +681,10 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
                 }
                 // dY row for class row ho and tap index tr: ho + tr + (ph + r0 - padT) / 2 (exact division)
                 const int offr = (ph + r0 - padT) / 2, offs = (pw + s0 - padT) / 2;
-                Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, Hc, Wc, 1, 1, -offr, 0, 0, (int64_t)g.B * Hc * Wc);
+                Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, Hc, Wc, 1, 1, -offr, 0, (int64_t)g.B * Hc * Wc);
                 if (offr != offs)
                     return fail(VAMD_EUNSUPPORTED, "conv_dgrad_mfma: unsupported stride-2 padding");
+                gp.kr = kr;
                 gp.ks = kc;
                 gp.Ktot = kr * kc * g.Cout;
                 gp.wr0 = r0; gp.ws0 = s0; gp.wstep = 2; gp.wk = g.k;
@@ -646,7 +700,7 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
     const int rowsH = g.up ? g.He : g.H, rowsW = g.up ? g.We : g.W;   // extents the GEMM rows enumerate
     const int64_t rows = (int64_t)g.B * rowsH * rowsW;
     const int padT = g.k - 1 - g.pad;
-    Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, rowsH, rowsW, g.k, 1, padT, 0, 0, rows);
+    Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, rowsH, rowsW, g.k, 1, padT, 0, rows);
     void* out = dx;
     const void* res = add;
     if (g.up) {
@@ -720,7 +774,7 @@ static int launch_tn(const Gather& gp, const T* dy, const T* x, int N, int lda, 
 }
 
 int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, hipStream_t st) {
-    Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, 0, g.M);
+    Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)g.Cout * gp.Ktot * sizeof(float), st);
     if (e != hipSuccess) return fail((int)e, "conv_wgrad_mfma: memset failed: %s", hipGetErrorString(e));
     if (dtype == VAMD_BF16)
@@ -745,7 +799,7 @@ int bmm_nt_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N,
                 int ldc, float alpha, int dtype, int out_f32, hipStream_t st) {
     // columns K..round_up(K) of both operands must be finite padding (zeros) owned by the caller
     const int Kc = round_up(K, dtype == VAMD_BF16 ? 8 : 4);
-    Gather gp = make_gather(1, M, Kc, 1, M, 1, M, 1, 1, 0, 0, 0, M);
+    Gather gp = make_gather(1, M, Kc, 1, M, 1, M, 1, 1, 0, 0, M);
     gp.ldx = lda;
     Epilogue ep{nullptr, nullptr, nullptr, nullptr, alpha, out_f32};
     if (dtype == VAMD_BF16)
@@ -765,7 +819,7 @@ int bmm_tn_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N,
     // the reduction axis K plays the pixel axis; A's columns (M) play dY's channels, B's columns (N)
     // play the gathered input's.  Padding columns up to the next 16-byte piece must be finite.
     const int piece = dtype == VAMD_BF16 ? 8 : 4;
-    Gather gp = make_gather(1, K, round_up(N, piece), 1, K, 1, K, 1, 1, 0, 0, 0, K);
+    Gather gp = make_gather(1, K, round_up(N, piece), 1, K, 1, K, 1, 1, 0, 0, K);
     gp.ldx = ldb;
     gp.Ktot = N;      // valid output columns
     if (dtype == VAMD_BF16)
