@@ -373,18 +373,28 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     x += (int64_t)blockIdx.z * strideB;
 
     // staging: in pass i this thread copies LDS piece i*256 + tid (the image of a direct-to-LDS
-    // load is lane-linear); the swizzle is applied to the piece it fetches
-    int a_row[NPASS_A], a_col[NPASS_A];                   // a_col < 0: nothing to fetch
+    // load is lane-linear); the swizzle is applied to the piece it fetches.  The pixel a pass reads
+    // advances by KP per K-step, so its (image, row, column) and its dY offset are carried along
+    // with adds and single-wrap compares; nothing is divided inside the loop.
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int step0 = blockIdx.y * steps_per_slice;
+    const int total_steps = (gp.M + KP - 1) / KP;
+    int step1 = step0 + steps_per_slice;
+    if (step1 > total_steps) step1 = total_steps;
+    const int kq_w = KP / gp.Wo, kr_w = KP - kq_w * gp.Wo;        // KP pixels = kq_w rows + kr_w columns
+    const int kq_h = kq_w / gp.Ho, kr_h = kq_w - kq_h * gp.Ho;    // kq_w rows = kq_h images + kr_h rows
+
+    int a_row[NPASS_A], a_off[NPASS_A];                   // a_row >= 2^30: nothing to fetch
 #pragma unroll
     for (int i = 0; i < NPASS_A; ++i) {
         const int pi = i * 256 + tid;
         const int row = pi / PPR_A, slot = pi - row * PPR_A;
         const int piece = BF16 ? (slot ^ tn_swizzle<ROWB_A>(row)) : slot;
         const int an = n0 + piece * PIECE;
-        a_row[i] = row;
-        a_col[i] = (an + PIECE <= lda && an < N) ? an : -1;
+        a_row[i] = (an + PIECE <= lda && an < N) ? row : (1 << 30);
+        a_off[i] = (step0 * KP + row) * lda + an;
     }
-    int b_row[NPASS_B], b_tr[NPASS_B], b_ts[NPASS_B], b_c[NPASS_B];
+    int b_row[NPASS_B], b_tr[NPASS_B], b_ts[NPASS_B], b_c[NPASS_B], b_img[NPASS_B], b_ho[NPASS_B], b_wo[NPASS_B];
 #pragma unroll
     for (int i = 0; i < NPASS_B; ++i) {
         const int pi = i * 256 + tid;
@@ -396,37 +406,48 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
         b_c[i] = bf - tap * gp.Cin;
         b_tr[i] = bf < gp.Ktot ? tap / gp.k : (1 << 20);  // out of range: the bounds test rejects it
         b_ts[i] = tap - (tap / gp.k) * gp.k;
+        const uint32_t m = (uint32_t)step0 * KP + row;
+        const uint32_t b = fdiv(m, gp.div_howo);
+        const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
+        const uint32_t ho = fdiv(rem, gp.div_wo);
+        b_img[i] = (int)b;
+        b_ho[i] = (int)ho;
+        b_wo[i] = (int)(rem - ho * gp.Wo);
     }
+    int mleft = gp.M - step0 * KP;                         // rows of the current K-step below this are real pixels
+    const int sshift = gp.stride - 1;
+    const T* zero = reinterpret_cast<const T*>(g_zero_page);
 
-    const int step0 = blockIdx.y * steps_per_slice;
-    const int total_steps = (gp.M + KP - 1) / KP;
-    int step1 = step0 + steps_per_slice;
-    if (step1 > total_steps) step1 = total_steps;
-
-    auto stage = [&](int buf, int step) {
-        unsigned char* sa = smem + buf * STAGE;
-        unsigned char* sb = sa + TILE_A;
+    auto stage_a = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < NPASS_A; ++i) {
-            const uint32_t m = (uint32_t)step * KP + a_row[i];
-            const T* srcA = (m < (uint32_t)gp.M && a_col[i] >= 0) ? dy + ((int64_t)m * lda + a_col[i])
-                                                                  : reinterpret_cast<const T*>(g_zero_page);
-            __builtin_amdgcn_global_load_lds(GPTR(srcA), LPTR(sa + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            const T* src = pick_ptr(a_row[i] < mleft, dy + (uint32_t)a_off[i], zero);
+            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sa + i * 4096), 16, 0, 0);
+            a_off[i] += KP * lda;
         }
+    };
+    auto stage_b = [&](int buf) {
+        unsigned char* sb = smem + buf * STAGE + TILE_A + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < NPASS_B; ++i) {
-            const uint32_t m = (uint32_t)step * KP + b_row[i];
-            const uint32_t b = fdiv(m, gp.div_howo);
-            const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
-            const uint32_t ho = fdiv(rem, gp.div_wo);
-            const int u = (int)ho * gp.stride - gp.pad + b_tr[i];
-            const int v = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad + b_ts[i];
-            bool ok = m < (uint32_t)gp.M && (unsigned)u < (unsigned)gp.He && (unsigned)v < (unsigned)gp.We;
-            const int hi = u >> gp.shift, wi = v >> gp.shift;
-            const T* srcB = ok ? x + ((((int64_t)b * gp.Hin + hi) * gp.Win + wi) * gp.ldx + b_c[i])
-                               : reinterpret_cast<const T*>(g_zero_page);
-            __builtin_amdgcn_global_load_lds(GPTR(srcB), LPTR(sb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            const int u = (b_ho[i] << sshift) - gp.pad + b_tr[i];       // stride is 1 or 2
+            const int v = (b_wo[i] << sshift) - gp.pad + b_ts[i];
+            const bool ok = (b_row[i] < mleft) & ((unsigned)u < (unsigned)gp.He) & ((unsigned)v < (unsigned)gp.We);
+            const uint32_t pix = __umul24(__umul24((uint32_t)b_img[i], (uint32_t)gp.Hin) + (uint32_t)(u >> gp.shift), (uint32_t)gp.Win) +
+                                 (uint32_t)(v >> gp.shift);
+            const T* src = pick_ptr(ok, x + (pix * (uint32_t)gp.ldx + (uint32_t)b_c[i]), zero);
+            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sb + i * 4096), 16, 0, 0);
+            // advance this pass by KP pixels
+            int wo = b_wo[i] + kr_w;
+            const int cw = wo >= gp.Wo ? 1 : 0;
+            b_wo[i] = wo - (cw ? gp.Wo : 0);
+            int ho = b_ho[i] + kr_h + cw;
+            const int ch = ho >= gp.Ho ? 1 : 0;
+            b_ho[i] = ho - (ch ? gp.Ho : 0);
+            b_img[i] += kq_h + ch;
         }
+        mleft -= KP;
     };
 
     f32x4_t acc[4][NJ];
@@ -435,79 +456,106 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    // bf16: one 16x16x32 MFMA k-step covers 32 pixels; lane l supplies row k0 + ((l&15)>>2),
+    // columns c0 + 4*(l&3) to the transposing read
+    auto read_frags = [&](int buf, int ks, bf16x8_t (&a)[4], bf16x8_t (&b)[NJ]) {
         const unsigned char* sa = smem + buf * STAGE;
         const unsigned char* sb = sa + TILE_A;
-        if constexpr (BF16) {
-            // 16x16x32 per k-step of 32 pixels; lane l supplies row k0 + ((l&15)>>2), cols c0 + 4*(l&3)
-            const int q = (lane & 15) >> 2, p = lane & 3, g = lane >> 4;
+        const int q = (lane & 15) >> 2, p = lane & 3, g = lane >> 4;
 #pragma unroll
-            for (int ks = 0; ks < KP / 32; ++ks) {
-                bf16x8_t a[4], b[NJ];
+        for (int h = 0; h < 2; ++h) {
+            const int row = ks * 32 + g * 8 + h * 4 + q;
+            const int swa = tn_swizzle<ROWB_A>(row), swb = tn_swizzle<ROWB_B>(row);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = ks * 32 + g * 8 + h * 4 + q;
-                    const int swa = tn_swizzle<ROWB_A>(row), swb = tn_swizzle<ROWB_B>(row);
+            for (int i = 0; i < 4; ++i) {
+                const int col = wm * 64 + i * 16 + p * 4;            // element column
+                const int pc = (col >> 3) ^ swa;                     // physical 16-byte piece
+                const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(sa + row * ROWB_A + pc * 16 + (col & 7) * 2));
+                const bf16x4_t fa = __builtin_bit_cast(bf16x4_t, va);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int col = wm * 64 + i * 16 + p * 4;            // element column
-                        const int pc = (col >> 3) ^ swa;                     // physical 16-byte piece
-                        const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t*)(sa + row * ROWB_A + pc * 16 + (col & 7) * 2));
-                        const bf16x4_t fa = __builtin_bit_cast(bf16x4_t, va);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = fa[e];
-                    }
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int colb = wn * (16 * NJ) + j * 16 + p * 4;
-                        const int pcb = (colb >> 3) ^ swb;
-                        const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t*)(sb + row * ROWB_B + pcb * 16 + (colb & 7) * 2));
-                        const bf16x4_t fb = __builtin_bit_cast(bf16x4_t, vb);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) b[j][h * 4 + e] = fb[e];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = fa[e];
             }
-        } else {
-            // 16x16x4 fp32: lane l holds A[i = l&15][k = l>>4]; tile rows are pixels, so element
-            // (k, i) sits at row k, column i: plain 4-byte reads, 16 consecutive lanes contiguous.
-            const int fr = lane & 15, g = lane >> 4;
 #pragma unroll
-            for (int ks = 0; ks < KP / 4; ++ks) {
-                const int row = ks * 4 + g;
-                float a[4], b[NJ];
+            for (int j = 0; j < NJ; ++j) {
+                const int colb = wn * (16 * NJ) + j * 16 + p * 4;
+                const int pcb = (colb >> 3) ^ swb;
+                const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(sb + row * ROWB_B + pcb * 16 + (colb & 7) * 2));
+                const bf16x4_t fb = __builtin_bit_cast(bf16x4_t, vb);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    a[i] = *reinterpret_cast<const float*>(sa + row * ROWB_A + (wm * 64 + i * 16 + fr) * 4);
+                for (int e = 0; e < 4; ++e) b[j][h * 4 + e] = fb[e];
+            }
+        }
+    };
+    auto mma = [&](const bf16x8_t (&a)[4], const bf16x8_t (&b)[NJ]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    // fp32: 16x16x4, lane l holds A[i = l&15][k = l>>4]; tile rows are pixels, so element (k, i)
+    // sits at row k, column i: plain 4-byte reads, 16 consecutive lanes contiguous.
+    auto compute_f32 = [&](int buf) {
+        const unsigned char* sa = smem + buf * STAGE;
+        const unsigned char* sb = sa + TILE_A;
+        const int fr = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < KP / 4; ++ks) {
+            const int row = ks * 4 + g;
+            float a[4], b[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const float*>(sa + row * ROWB_A + (wm * 64 + i * 16 + fr) * 4);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                b[j] = *reinterpret_cast<const float*>(sb + row * ROWB_B + (wn * (16 * NJ) + j * 16 + fr) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    b[j] = *reinterpret_cast<const float*>(sb + row * ROWB_B + (wn * (16 * NJ) + j * 16 + fr) * 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto compute = [&](int buf) {
+        if constexpr (BF16) {
+            bf16x8_t a[4], b[NJ];
+            read_frags(buf, 0, a, b);
+            mma(a, b);
+            read_frags(buf, 1, a, b);
+            mma(a, b);
+        } else {
+            compute_f32(buf);
         }
     };
 
     if (step0 < step1) {
-        stage(0, step0);
+        stage_a(0);
+        stage_b(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int t = step0; t < step1; ++t) {
-            if (t + 1 < step1) stage((t + 1 - step0) & 1, t + 1);
-            compute((t - step0) & 1);
+        // steady state: fragment reads of K-step t, address arithmetic + direct-to-LDS loads of
+        // K-step t+1 between them and the MFMAs (LDS reads and LDS-DMA loads keep program order)
+        for (int t = step0; t + 1 < step1; ++t) {
+            const int cur = (t - step0) & 1, nxt = cur ^ 1;
+            if constexpr (BF16) {
+                bf16x8_t a[4], b[NJ];
+                read_frags(cur, 0, a, b);
+                stage_a(nxt);
+                mma(a, b);
+                read_frags(cur, 1, a, b);
+                stage_b(nxt);
+                mma(a, b);
+            } else {
+                stage_a(nxt);
+                stage_b(nxt);
+                compute_f32(cur);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        compute((step1 - 1 - step0) & 1);
     }
 
     // D layout: column (second operand index) = lane & 15, row (first operand index) = 4*(lane>>4)+r
