@@ -57,6 +57,18 @@ int vamd_conv2d_fwd(const vamd_conv_desc* d, const void* x, const void* w, const
                     const float* temb, const void* residual, const void* residual2, void* y,
                     void* stream);
 
+/* vamd_conv2d_fwd that also emits what a BatchNorm2d over its output needs in training mode
+ * (reference models/ddpm.py:52-53: block2 = BatchNorm2d(out) -> act -> Dropout -> Conv2d runs
+ * on the output of block1's convolution; :47-48 the same for the next block's block1):
+ * stats[part][Cout][2] (fp32) = per row tile, the column sums of y and y*y over the values as
+ * stored (rounded to the compute dtype).  vamd_conv2d_stats_parts(d) gives the number of parts,
+ * 0 if the kernel serving this descriptor cannot produce them (use vamd_chan_stats then).
+ * vamd_fold_partials + vamd_bn_finalize turn the parts into scale/shift. */
+int vamd_conv2d_fwd_stats(const vamd_conv_desc* d, const void* x, const void* w, const float* bias,
+                          const float* temb, const void* residual, const void* residual2, void* y,
+                          float* stats, void* stream);
+int vamd_conv2d_stats_parts(const vamd_conv_desc* d);
+
 /* dx = conv_transpose(dy, w) (+ add).  `w_t` is the weight packed for the input gradient,
  * [Cin][kh][kw][Cout] with both kernel axes flipped (vamd_repack_weight makes it).
  * `add` (same shape as dx, may be NULL) is summed in: the second gradient stream of a residual.
@@ -67,9 +79,12 @@ int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, 
  * fused upsample is formed at the upsampled resolution first). */
 size_t vamd_conv2d_dgrad_workspace(const vamd_conv_desc* d);
 
-/* dw[Cout][kh][kw][Cin] (fp32) = sum over pixels of dy (x) x.  Overwrites dw.  `workspace` must
- * hold vamd_conv2d_wgrad_workspace(d) bytes (partial sums of the thin-channel kernels; 0 otherwise). */
-int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw,
+/* dw[Cout][kh][kw][Cin] (fp32) = sum over pixels of dy (x) x.  Overwrites dw.  If `dbias` is not
+ * NULL, dbias[Cout] (fp32) = sum over pixels of dy is written too: the bias gradient comes out of
+ * the same pass over dy (the MFMA kernel multiplies the staged dy tile by a column of ones).
+ * `workspace` must hold vamd_conv2d_wgrad_workspace(d) bytes (partial sums of the thin-channel
+ * kernels; 0 otherwise). */
+int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
                       void* workspace, size_t workspace_bytes, void* stream);
 size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d);
 
@@ -136,6 +151,11 @@ int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const f
  * Used for the gradients of conv bias and of the projected time embedding. */
 int vamd_sum_finalize(const float* partial, int nchunk, int G, int C, float* per_g, float* total,
                       void* stream);
+
+/* out[q][width] = sum over parts p = q, q + nout, q + 2*nout, ... of in[p][width], in that order
+ * (deterministic).  Shrinks the per-row-tile statistics of vamd_conv2d_fwd_stats (tens of
+ * thousands of parts at 224x224) to the few hundred the finalize kernels read. */
+int vamd_fold_partials(const float* in, int nparts, int width, int nout, float* out, void* stream);
 
 /* ------------------------------------------------------------------- attention core
  * Batched products with padded rows: lda/ldb/ldc are element strides between rows, batch z of an

@@ -51,6 +51,7 @@ def main():
         dx = torch.empty_like(x)
         dw = torch.empty((Cout, k, k, Cin), device=DEV, dtype=torch.float32)
         bias = torch.randn(Cout, device=DEV)
+        dbias = torch.empty(Cout, device=DEV)
         nb1 = lib.vamd_conv2d_dgrad_workspace(C.byref(d))
         nb2 = lib.vamd_conv2d_wgrad_workspace(C.byref(d))
         ws = torch.empty(max(nb1, nb2, 16), dtype=torch.uint8, device=DEV)
@@ -58,7 +59,7 @@ def main():
         io = 2.0 * (x.numel() + y.numel())
         t_f = timeit(lambda: call("vamd_conv2d_fwd", C.byref(d), x.data_ptr(), wf.data_ptr(), bias.data_ptr(), None, None, None, y.data_ptr(), st))
         t_d = timeit(lambda: call("vamd_conv2d_dgrad", C.byref(d), dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), ws.data_ptr(), nb1, st))
-        t_w = timeit(lambda: call("vamd_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb2, st))
+        t_w = timeit(lambda: call("vamd_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbias.data_ptr(), ws.data_ptr(), nb2, st))
         row = "  ".join("%s %8.1f us %7.1f TF %6.0f GB/s" % (n, t, flops / t / 1e6, io / t / 1e3)
                         for n, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)))
         print("%-34s %s" % (cs, row), flush=True)

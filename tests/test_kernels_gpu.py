@@ -139,6 +139,24 @@ def test_conv_fwd_dgrad_wgrad(case, dts, algo):
     call("vamd_conv2d_fwd", C.byref(d), P(xn), P(wf), P(bias.to(DEV)), P(temb.to(DEV)), P(nhwc(res)), P(nhwc(res2)), P(y), S())
     assert relerr(y.permute(0, 3, 1, 2), full64.detach()) < TOL_OUT[dts]
 
+    # statistics fused into the epilogue: column sums of the stored outputs and of their squares
+    nparts = lib.vamd_conv2d_stats_parts(C.byref(d))
+    assert (nparts > 0) == bool(lib.vamd_conv2d_uses_mfma(C.byref(d), 0))
+    if nparts > 0:
+        y2 = torch.empty_like(y)
+        part = torch.full((nparts, Cout, 2), 7.0, dtype=torch.float32, device=DEV)
+        call("vamd_conv2d_fwd_stats", C.byref(d), P(xn), P(wf), P(bias.to(DEV)), P(temb.to(DEV)), P(nhwc(res)),
+             P(nhwc(res2)), P(y2), P(part), S())
+        assert torch.equal(y2, y)
+        yd = y.double().cpu().reshape(-1, Cout)
+        want = torch.stack([yd.sum(0), (yd * yd).sum(0)], 1)
+        assert relerr(part.sum(0), want) < 1e-5
+        nout = min(3, nparts)
+        folded = torch.full((nout, Cout, 2), 7.0, dtype=torch.float32, device=DEV)
+        call("vamd_fold_partials", P(part), nparts, 2 * Cout, nout, P(folded), S())
+        assert relerr(folded.sum(0), want) < 1e-5
+        assert relerr(folded[0], part[0::nout].sum(0)) < 1e-6
+
     dy, dy64 = rnd((B, Cout, Ho, Wo), tdt, gen)
     gx64, gw64 = torch.autograd.grad(y64, [x64, w64], dy64)
     add, add64 = rnd((B, Cin, H, W), tdt, gen)
@@ -154,7 +172,12 @@ def test_conv_fwd_dgrad_wgrad(case, dts, algo):
     dwk = torch.full((Cout, k, k, Cin), 7.0, dtype=torch.float32, device=DEV)   # must be overwritten
     wbytes = lib.vamd_conv2d_wgrad_workspace(C.byref(d))
     wws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=DEV)
-    call("vamd_conv2d_wgrad", C.byref(d), P(dyn), P(xn), P(dwk), P(wws), wbytes, S())
+    dbk = torch.full((Cout,), 7.0, dtype=torch.float32, device=DEV)             # bias gradient, overwritten too
+    call("vamd_conv2d_wgrad", C.byref(d), P(dyn), P(xn), P(dwk), P(dbk), P(wws), wbytes, S())
+    assert relerr(dbk, dy64.sum((0, 2, 3))) < TOL_F32OUT[dts]
+    dwk2 = torch.full((Cout, k, k, Cin), 7.0, dtype=torch.float32, device=DEV)  # without the bias output
+    call("vamd_conv2d_wgrad", C.byref(d), P(dyn), P(xn), P(dwk2), None, P(wws), wbytes, S())
+    assert relerr(dwk2, dwk) < 1e-6
     dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=DEV)
     call("vamd_unpack_wgrad", P(dwk), P(dw), Cout, Cin, k, S())
     assert relerr(dw, gw64) < TOL_F32OUT[dts]

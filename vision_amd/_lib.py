@@ -42,9 +42,12 @@ SIGNATURES = {
     "vamd_last_error": (C.c_char_p, []),
     "vamd_version": (_i, []),
     "vamd_conv2d_fwd": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "vamd_conv2d_fwd_stats": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "vamd_conv2d_stats_parts": (_i, [_d]),
+    "vamd_fold_partials": (_i, [_p, _i, _i, _i, _p, _p]),
     "vamd_conv2d_dgrad": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
     "vamd_conv2d_dgrad_workspace": (_z, [_d]),
-    "vamd_conv2d_wgrad": (_i, [_d, _p, _p, _p, _p, _z, _p]),
+    "vamd_conv2d_wgrad": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
     "vamd_conv2d_wgrad_workspace": (_z, [_d]),
     "vamd_conv2d_uses_mfma": (_i, [_d, _i]),
     "vamd_repack_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

@@ -36,6 +36,46 @@ int conv_geom(const vamd_conv_desc* d, ConvGeom* g, const char* who) {
 using namespace vamd;
 
 namespace {
+// out[c] = sum over rows of t[row][c] for C <= 256.  A block's 256 threads cover RPB = 256 / C whole
+// rows at a time (thread = (row lane, column), consecutive threads on consecutive addresses), the
+// row lanes are folded through LDS, one atomic per block and column.
+template <typename T>
+__global__ void __launch_bounds__(256)
+column_sums_kernel(const T* __restrict__ t, int64_t rows, int C, int ld, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int rpb = 256 / C;
+    const int rl = threadIdx.x / C, c = threadIdx.x - rl * C;
+    float acc = 0.f;
+    if (rl < rpb) {
+        const int64_t step = (int64_t)gridDim.x * rpb;
+        int64_t r = (int64_t)blockIdx.x * rpb + rl;
+        for (; r + 3 * step < rows; r += 4 * step)
+            acc += (to_f(t[r * ld + c]) + to_f(t[(r + step) * ld + c])) + (to_f(t[(r + 2 * step) * ld + c]) + to_f(t[(r + 3 * step) * ld + c]));
+        for (; r < rows; r += step) acc += to_f(t[r * ld + c]);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float sum = 0.f;
+        for (int q = 0; q < rpb; ++q) sum += red[q * C + threadIdx.x];
+        atomicAdd(out + threadIdx.x, sum);
+    }
+}
+
+int column_sums(int dtype, const void* t, int64_t rows, int C, float* out, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st);
+    if (e != hipSuccess) return fail((int)e, "column_sums: memset failed: %s", hipGetErrorString(e));
+    VAMD_DISPATCH(dtype, "column_sums", {
+        for (int c0 = 0; c0 < C; c0 += 256) {          // 256 columns per launch
+            const int cw = C - c0 < 256 ? C - c0 : 256;
+            hipLaunchKernelGGL((column_sums_kernel<T>), dim3(grid_for(rows, 64, 2048)), dim3(256), 0, st,
+                               (const T*)t + c0, rows, cw, C, out + c0);
+        }
+    });
+    VAMD_LAUNCH_OK("column_sums");
+    return 0;
+}
+
 // algo: 0 auto (thin -> MFMA -> direct), 1 direct, 2 MFMA, 3 thin
 enum { kAuto = 0, kDirect = 1, kMfma = 2, kThin = 3 };
 
@@ -57,20 +97,42 @@ int pick(int algo, bool thin_ok, bool mfma_ok, const char* who, const ConvGeom& 
 
 extern "C" {
 
+static int conv2d_fwd_impl(const char* who, const vamd_conv_desc* d, const void* x, const void* w, const float* bias,
+                           const float* temb, const void* residual, const void* residual2, void* y, float* stats,
+                           void* stream) {
+    ConvGeom g;
+    int rc = conv_geom(d, &g, who);
+    if (rc) return rc;
+    VAMD_REQUIRE(x && w && y, "%s: null tensor", who);
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)y % 16 == 0,
+                 "%s: tensors must be 16-byte aligned", who);
+    const int a = pick(d->algo, conv_thin_supported(g, d->dtype), conv_fwd_mfma_supported(g, d->dtype), who, g);
+    if (a < 0) return a;
+    if (stats && a != kMfma)
+        return fail(VAMD_EUNSUPPORTED, "%s: fused statistics need the MFMA kernel (vamd_conv2d_stats_parts says 0)", who);
+    if (a == kThin) return conv_fwd_thin(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
+    if (a == kMfma) return conv_fwd_mfma(g, d->dtype, x, w, bias, temb, residual, residual2, y, stats, as_stream(stream));
+    return conv_fwd_direct(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
+}
+
 int vamd_conv2d_fwd(const vamd_conv_desc* d, const void* x, const void* w, const float* bias,
                     const float* temb, const void* residual, const void* residual2, void* y,
                     void* stream) {
+    return conv2d_fwd_impl("vamd_conv2d_fwd", d, x, w, bias, temb, residual, residual2, y, nullptr, stream);
+}
+
+int vamd_conv2d_fwd_stats(const vamd_conv_desc* d, const void* x, const void* w, const float* bias,
+                          const float* temb, const void* residual, const void* residual2, void* y,
+                          float* stats, void* stream) {
+    VAMD_REQUIRE(stats, "vamd_conv2d_fwd_stats: null statistics buffer");
+    return conv2d_fwd_impl("vamd_conv2d_fwd_stats", d, x, w, bias, temb, residual, residual2, y, stats, stream);
+}
+
+int vamd_conv2d_stats_parts(const vamd_conv_desc* d) {
     ConvGeom g;
-    int rc = conv_geom(d, &g, "vamd_conv2d_fwd");
-    if (rc) return rc;
-    VAMD_REQUIRE(x && w && y, "vamd_conv2d_fwd: null tensor");
-    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)y % 16 == 0,
-                 "vamd_conv2d_fwd: tensors must be 16-byte aligned");
-    const int a = pick(d->algo, conv_thin_supported(g, d->dtype), conv_fwd_mfma_supported(g, d->dtype), "vamd_conv2d_fwd", g);
-    if (a < 0) return a;
-    if (a == kThin) return conv_fwd_thin(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
-    if (a == kMfma) return conv_fwd_mfma(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
-    return conv_fwd_direct(g, d->dtype, x, w, bias, temb, residual, residual2, y, as_stream(stream));
+    if (conv_geom(d, &g, "vamd_conv2d_stats_parts")) return 0;
+    const int a = pick(d->algo, conv_thin_supported(g, d->dtype), conv_fwd_mfma_supported(g, d->dtype), "", g);
+    return a == kMfma ? conv_fwd_mfma_stats_parts(g) : 0;
 }
 
 int vamd_conv2d_uses_mfma(const vamd_conv_desc* d, int pass) {
@@ -112,8 +174,8 @@ size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d) {
     return a == kThin ? conv_wgrad_thin_workspace(g, d->dtype) : 0;
 }
 
-int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
+                      void* workspace, size_t workspace_bytes, void* stream) {
     ConvGeom g;
     int rc = conv_geom(d, &g, "vamd_conv2d_wgrad");
     if (rc) return rc;
@@ -122,8 +184,12 @@ int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, fl
                  "vamd_conv2d_wgrad: tensors must be 16-byte aligned");
     const int a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), "vamd_conv2d_wgrad", g);
     if (a < 0) return a;
+    if (a == kMfma) return conv_wgrad_mfma(g, d->dtype, dy, x, dw, dbias, as_stream(stream));
+    if (dbias) {                     // the other kernels do not produce it: one extra pass over dy
+        rc = column_sums(d->dtype, dy, g.M, g.Cout, dbias, as_stream(stream));
+        if (rc) return rc;
+    }
     if (a == kThin) return conv_wgrad_thin(g, d->dtype, dy, x, dw, workspace, workspace_bytes, as_stream(stream));
-    if (a == kMfma) return conv_wgrad_mfma(g, d->dtype, dy, x, dw, as_stream(stream));
     return conv_wgrad_direct(g, d->dtype, dy, x, dw, as_stream(stream));
 }
 

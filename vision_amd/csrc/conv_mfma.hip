@@ -65,6 +65,7 @@ struct Epilogue {
     const void* res2;
     float alpha;
     int out_f32;           // store fp32 instead of T
+    float* stats;          // [row tiles][N][2]: per row tile, column sums of the stored y and y*y (or NULL)
 };
 
 // Branch-free pointer select: keeps the staging code of a K-step in one basic block, so that the
@@ -274,6 +275,9 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
     const int n = n0 + grp * PIECE;
     // a trailing partial group (N not a multiple of PIECE) is written whole: its extra columns are
     // exact zeros (their weight rows were never loaded) and ldc leaves room for them
+    float s1[PIECE], s2[PIECE];                           // column sums of what this thread stores
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     if (n < N && n + PIECE <= ldc) {
         float bv[PIECE];
 #pragma unroll
@@ -325,7 +329,32 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
 #pragma unroll
                 for (int e = 0; e < PIECE; ++e) ov.v[e] = from_f<T>(v[e]);
                 *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + off) = ov;
+                if (ep.stats) {                           // statistics of the rounded values a later pass would read
+#pragma unroll
+                    for (int e = 0; e < PIECE; ++e) {
+                        const float r = to_f(ov.v[e]);
+                        s1[e] += r;
+                        s2[e] = fmaf(r, r, s2[e]);
+                    }
+                }
             }
+        }
+    }
+    if (ep.stats) {                                       // uniform: fold the 256/G row groups through LDS
+        __syncthreads();
+        float* red = tile;                                // [256/G][BN][2]
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+            red[((tid / G) * BN + grp * PIECE + e) * 2 + 0] = s1[e];
+            red[((tid / G) * BN + grp * PIECE + e) * 2 + 1] = s2[e];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BN * 2; idx += 256) {
+            const int col = idx >> 1;
+            float sum = 0.f;
+#pragma unroll 4
+            for (int rr = 0; rr < 256 / G; ++rr) sum += red[rr * BN * 2 + idx];
+            if (n0 + col < N) ep.stats[((int64_t)mt * N + n0 + col) * 2 + (idx & 1)] = sum;
         }
     }
 }
@@ -350,7 +379,7 @@ __global__ void __launch_bounds__(256, 2)
 conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x, int N, int lda, int ldc,
                     float* __restrict__ dw, int n_tiles, int f_tiles, int steps_per_slice,
                     int64_t strideA, int64_t strideB, int64_t strideC, int out_mode, void* yout,
-                    float alpha) {
+                    float alpha, float* __restrict__ dbias) {
     constexpr int PIECE = ElemTraits<T>::PIECE;
     constexpr bool BF16 = sizeof(T) == 2;
     constexpr int KP = BF16 ? 64 : 32;                    // pixels per K-step
@@ -455,6 +484,12 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // bias gradient: the workgroups of the first filter-column tile also multiply dY^T by a column
+    // of ones (every column of the product is the per-channel pixel sum)
+    const bool do_bias = dbias != nullptr && ft == 0 && wn == 0;      // wave-uniform
+    f32x4_t accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // bf16: one 16x16x32 MFMA k-step covers 32 pixels; lane l supplies row k0 + ((l&15)>>2),
     // columns c0 + 4*(l&3) to the transposing read
@@ -494,6 +529,13 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+            bf16x8_t ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+        }
     };
     // fp32: 16x16x4, lane l holds A[i = l&15][k = l>>4]; tile rows are pixels, so element (k, i)
     // sits at row k, column i: plain 4-byte reads, 16 consecutive lanes contiguous.
@@ -516,6 +558,10 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], 1.0f, accb[i], 0, 0, 0);
+            }
         }
     };
     auto compute = [&](int buf) {
@@ -560,6 +606,15 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 
     // D layout: column (second operand index) = lane & 15, row (first operand index) = 4*(lane>>4)+r
     const int fr = lane & 15, fq = lane >> 4;
+    if (do_bias && fr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nrow = n0 + wm * 64 + i * 16 + fq * 4 + r;
+                if (nrow < N) atomicAdd(dbias + nrow, accb[i][r]);
+            }
+    }
     if (out_mode == 0) {
         // dW[n][f] fp32, atomically accumulated across split-K slices
 #pragma unroll
@@ -656,10 +711,12 @@ bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype) {
     return nt_shape_ok(g.Cin, g.Cout, g.M, dtype);
 }
 
+int conv_fwd_mfma_stats_parts(const ConvGeom& g) { return (int)((g.M + kBM - 1) / kBM); }
+
 int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
-                  const float* temb, const void* res, const void* res2, void* y, hipStream_t st) {
+                  const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st) {
     Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
-    Epilogue ep{bias, temb, res, res2, 1.0f, 0};
+    Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats};
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
     return run_nt<float>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
 }
@@ -737,7 +794,7 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
                 gp.Ktot = kr * kc * g.Cout;
                 gp.wr0 = r0; gp.ws0 = s0; gp.wstep = 2; gp.wk = g.k;
                 gp.oH = g.H; gp.oW = g.W; gp.ostep = 2; gp.oph = ph; gp.opw = pw;
-                Epilogue ep{nullptr, nullptr, add, nullptr, 1.0f, 0};
+                Epilogue ep{nullptr, nullptr, add, nullptr, 1.0f, 0, nullptr};
                 const int ldw = g.k * g.k * g.Cout;
                 int rc = dtype == VAMD_BF16 ? run_nt<bf16_t>(gp, dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st)
                                             : run_nt<float>(gp, dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st);
@@ -757,7 +814,7 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
         out = workspace;
         res = nullptr;
     }
-    Epilogue ep{nullptr, nullptr, res, nullptr, 1.0f, 0};
+    Epilogue ep{nullptr, nullptr, res, nullptr, 1.0f, 0, nullptr};
     int rc = dtype == VAMD_BF16 ? run_nt<bf16_t>(gp, dy, wt, g.Cin, gp.Ktot, g.Cin, ep, out, 1, 0, 0, 0, st)
                                 : run_nt<float>(gp, dy, wt, g.Cin, gp.Ktot, g.Cin, ep, out, 1, 0, 0, 0, st);
     if (rc) return rc;
@@ -783,7 +840,8 @@ bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype) {
 
 template <typename T, int AN, int BF>
 static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
-                           int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, hipStream_t st) {
+                           int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, float* dbias,
+                           hipStream_t st) {
     constexpr int KP = sizeof(T) == 2 ? 64 : 32;
     constexpr int LDS = 2 * KP * (AN + BF) * (int)sizeof(T);
     static bool configured = false;
@@ -807,27 +865,30 @@ static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int
     slices = (total_steps + steps_per - 1) / steps_per;
     dim3 grid(n_tiles * f_tiles, slices, batch);
     hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
-                       f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha);
+                       f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias);
     VAMD_LAUNCH_OK("conv_tn_mfma");
     return 0;
 }
 
 template <typename T>
 static int launch_tn(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
-                     int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, hipStream_t st) {
+                     int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, float* dbias,
+                     hipStream_t st) {
     // narrow outputs (Cout <= 64): a 64 x 192 tile wastes no MFMA rows and 192 divides 9*Cin
     if (out_mode == 0 && N <= 64 && gp.Ktot >= 192)
-        return launch_tn_shape<T, 64, 192>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, st);
-    return launch_tn_shape<T, 128, 128>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, st);
+        return launch_tn_shape<T, 64, 192>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, st);
+    return launch_tn_shape<T, 128, 128>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, st);
 }
 
-int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, hipStream_t st) {
+int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
+                    hipStream_t st) {
     Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)g.Cout * gp.Ktot * sizeof(float), st);
+    if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)g.Cout * sizeof(float), st);
     if (e != hipSuccess) return fail((int)e, "conv_wgrad_mfma: memset failed: %s", hipGetErrorString(e));
     if (dtype == VAMD_BF16)
-        return launch_tn<bf16_t>(gp, (const bf16_t*)dy, (const bf16_t*)x, g.Cout, g.Cout, gp.Ktot, dw, 1, 0, 0, 0, 0, nullptr, 1.f, st);
-    return launch_tn<float>(gp, (const float*)dy, (const float*)x, g.Cout, g.Cout, gp.Ktot, dw, 1, 0, 0, 0, 0, nullptr, 1.f, st);
+        return launch_tn<bf16_t>(gp, (const bf16_t*)dy, (const bf16_t*)x, g.Cout, g.Cout, gp.Ktot, dw, 1, 0, 0, 0, 0, nullptr, 1.f, dbias, st);
+    return launch_tn<float>(gp, (const float*)dy, (const float*)x, g.Cout, g.Cout, gp.Ktot, dw, 1, 0, 0, 0, 0, nullptr, 1.f, dbias, st);
 }
 
 // Batched products for the attention core on the same kernels.  Rows may be padded: lda/ldb/ldc
@@ -849,7 +910,7 @@ int bmm_nt_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N,
     const int Kc = round_up(K, dtype == VAMD_BF16 ? 8 : 4);
     Gather gp = make_gather(1, M, Kc, 1, M, 1, M, 1, 1, 0, 0, M);
     gp.ldx = lda;
-    Epilogue ep{nullptr, nullptr, nullptr, nullptr, alpha, out_f32};
+    Epilogue ep{nullptr, nullptr, nullptr, nullptr, alpha, out_f32, nullptr};
     if (dtype == VAMD_BF16)
         return run_nt<bf16_t>(gp, A, Bm, N, ldb, ldc, ep, C, batch, (int64_t)M * lda, (int64_t)N * ldb, (int64_t)M * ldc, st);
     return run_nt<float>(gp, A, Bm, N, ldb, ldc, ep, C, batch, (int64_t)M * lda, (int64_t)N * ldb, (int64_t)M * ldc, st);
@@ -872,9 +933,9 @@ int bmm_tn_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N,
     gp.Ktot = N;      // valid output columns
     if (dtype == VAMD_BF16)
         return launch_tn<bf16_t>(gp, (const bf16_t*)A, (const bf16_t*)Bm, M, lda, ldc, nullptr, batch, (int64_t)K * lda,
-                                 (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, st);
+                                 (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, nullptr, st);
     return launch_tn<float>(gp, (const float*)A, (const float*)Bm, M, lda, ldc, nullptr, batch, (int64_t)K * lda,
-                            (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, st);
+                            (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, nullptr, st);
 }
 
 }  // namespace vamd

@@ -48,13 +48,14 @@ int thin_wgrad_mfma(const ConvGeom& g, const void* dy, const void* x, float* dw,
 // MFMA implicit-GEMM kernels (conv_mfma.hip).  *_supported says whether the shape is covered.
 bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype);
 int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
-                  const float* temb, const void* res, const void* res2, void* y, hipStream_t st);
+                  const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st);
+int conv_fwd_mfma_stats_parts(const ConvGeom& g);      // row tiles = leading extent of `stats`
 bool conv_dgrad_mfma_supported(const ConvGeom& g, int dtype);
 size_t conv_dgrad_mfma_workspace(const ConvGeom& g, int dtype);
 int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt, const void* add,
                     void* dx, void* workspace, size_t workspace_bytes, hipStream_t st);
 bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype);
-int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw,
+int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
                     hipStream_t st);
 
 // batched products for the attention core on the MFMA kernels (rows may be padded: ld = row stride)

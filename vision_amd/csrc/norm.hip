@@ -265,6 +265,24 @@ sum_over_g_kernel(const float* __restrict__ partial, int nchunk, int G, int C,
     if (total1) total1[c] = (float)((red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
 }
 
+// out[q][w] = sum of in[p][w] over p = q, q + nout, ...; threads run along w (coalesced rows)
+__global__ void __launch_bounds__(256)
+fold_partials_kernel(const float* __restrict__ in, int nparts, int width, int nout, float* __restrict__ out) {
+    const int q = blockIdx.x;
+    const int w = blockIdx.y * 256 + threadIdx.x;
+    if (w >= width) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int p = q;
+    for (; p + 3 * nout < nparts; p += 4 * nout) {
+        a0 += in[(int64_t)p * width + w];
+        a1 += in[(int64_t)(p + nout) * width + w];
+        a2 += in[(int64_t)(p + 2 * nout) * width + w];
+        a3 += in[(int64_t)(p + 3 * nout) * width + w];
+    }
+    for (; p < nparts; p += nout) a0 += in[(int64_t)p * width + w];
+    out[(int64_t)q * width + w] = (a0 + a1) + (a2 + a3);
+}
+
 template <typename T, int VEC>
 __global__ void scale_shift_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                        const float* __restrict__ shift, const T* __restrict__ mask,
@@ -501,6 +519,14 @@ int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const f
         }
     });
     VAMD_LAUNCH_OK("vamd_norm_bwd_apply");
+    return 0;
+}
+
+int vamd_fold_partials(const float* in, int nparts, int width, int nout, float* out, void* stream) {
+    VAMD_REQUIRE(in && out && nparts > 0 && width > 0 && nout > 0 && nout <= nparts, "vamd_fold_partials: bad argument");
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(nout, (width + 255) / 256), dim3(256), 0, as_stream(stream), in,
+                       nparts, width, nout, out);
+    VAMD_LAUNCH_OK("vamd_fold_partials");
     return 0;
 }
 

@@ -79,15 +79,32 @@ class _Conv:
                      (("fwd", "dgrad", "wgrad")[which], self.cin, self.cout, self.k, self.stride, int(self.up), B, H, W)))
         return e1
 
-    def fwd(self, x, temb=None, res=None, res2=None, bias=True):
+    def fwd(self, x, temb=None, res=None, res2=None, bias=True, want_stats=False):
+        """y = conv(x) + bias (+ temb + res + res2).  With want_stats, the kernel's epilogue also
+        leaves the per-channel sums of y and y*y (what a train-mode BatchNorm over y needs) in
+        eng.stats_for[y.data_ptr()], if the kernel serving this shape can produce them."""
         B, H, W, _ = x.shape
         Ho, Wo = self.out_hw(H, W)
-        y = torch.empty((B, Ho, Wo, self.cout), dtype=self.eng.dtype, device=x.device)
+        e = self.eng
+        y = torch.empty((B, Ho, Wo, self.cout), dtype=e.dtype, device=x.device)
+        d = self.desc(B, H, W)
+        nparts = lib.vamd_conv2d_stats_parts(C.byref(d)) if want_stats else 0
         ev = self._timed(0, B, H, W)
-        call("vamd_conv2d_fwd", C.byref(self.desc(B, H, W)), _ptr(x), _ptr(self.wf),
-             _ptr(self.b) if bias else None, _ptr(temb), _ptr(res), _ptr(res2), _ptr(y), _stream())
+        if nparts > 0:
+            part = torch.empty((nparts, self.cout, 2), dtype=torch.float32, device=x.device)
+            call("vamd_conv2d_fwd_stats", C.byref(d), _ptr(x), _ptr(self.wf), _ptr(self.b) if bias else None,
+                 _ptr(temb), _ptr(res), _ptr(res2), _ptr(y), _ptr(part), _stream())
+        else:
+            call("vamd_conv2d_fwd", C.byref(d), _ptr(x), _ptr(self.wf),
+                 _ptr(self.b) if bias else None, _ptr(temb), _ptr(res), _ptr(res2), _ptr(y), _stream())
         if ev is not None:
             ev.record()
+        if nparts > 0:
+            if nparts > 512:                      # tens of thousands of row tiles at full resolution
+                folded = torch.empty((128, self.cout, 2), dtype=torch.float32, device=x.device)
+                call("vamd_fold_partials", _ptr(part), nparts, 2 * self.cout, 128, _ptr(folded), _stream())
+                part, nparts = folded, 128
+            e.stats_for[y.data_ptr()] = (part, nparts)
         return y
 
     def dgrad(self, dy, in_shape, add=None):
@@ -103,19 +120,22 @@ class _Conv:
             ev.record()
         return dx
 
-    def wgrad(self, dy, x):
+    def wgrad(self, dy, x, bias=True):
+        """Weight gradient into the arena; with bias=True the bias gradient (column sums of dy)
+        comes out of the same launch."""
         B, H, W, _ = x.shape
+        gb = _ptr(self.gb) if bias else None
         ev = self._timed(2, B, H, W)
         d = self.desc(B, H, W)
         nbytes = lib.vamd_conv2d_wgrad_workspace(C.byref(d))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
         if self.k == 1:
-            call("vamd_conv2d_wgrad", C.byref(d), _ptr(dy), _ptr(x), _ptr(self.gw), _ptr(ws), nbytes, _stream())
+            call("vamd_conv2d_wgrad", C.byref(d), _ptr(dy), _ptr(x), _ptr(self.gw), gb, _ptr(ws), nbytes, _stream())
             if ev is not None:
                 ev.record()
         else:
             tmp = torch.empty(self.gw.numel(), dtype=torch.float32, device=x.device)
-            call("vamd_conv2d_wgrad", C.byref(d), _ptr(dy), _ptr(x), _ptr(tmp), _ptr(ws), nbytes, _stream())
+            call("vamd_conv2d_wgrad", C.byref(d), _ptr(dy), _ptr(x), _ptr(tmp), gb, _ptr(ws), nbytes, _stream())
             if ev is not None:
                 ev.record()
             call("vamd_unpack_wgrad", _ptr(tmp), _ptr(self.gw), self.cout, self.cin, self.k, _stream())
@@ -163,9 +183,13 @@ class _Norm:
             call("vamd_bn_finalize", None, 0, Cc, 0, _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm),
                  _ptr(self.rv), None, BN_MOMENTUM, BN_EPS, 0, _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs), _stream())
         else:
-            nchunk = lib.vamd_stats_chunks(R, G)
-            part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=dev)
-            call("vamd_chan_stats", _ptr(x), _ptr(part), G, R, Cc, e.dt, _stream())
+            fused = e.stats_for.pop(x.data_ptr(), None) if self.bn else None
+            if fused is not None:                 # the producing convolution already summed y and y*y
+                part, nchunk = fused
+            else:
+                nchunk = lib.vamd_stats_chunks(R, G)
+                part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=dev)
+                call("vamd_chan_stats", _ptr(x), _ptr(part), G, R, Cc, e.dt, _stream())
             if self.bn:
                 call("vamd_bn_finalize", _ptr(part), nchunk, Cc, R, _ptr(self.gamma), _ptr(self.beta),
                      _ptr(self.rm), _ptr(self.rv), _ptr(self.nbt), BN_MOMENTUM, BN_EPS, 1, _ptr(sc),
@@ -228,16 +252,16 @@ class _ResBlock:
         self.short = _Conv(eng, p + ".layers.0", spec.cin, spec.cout, 1) if spec.cin != spec.cout else None
         self.convs = [c for c in (self.conv1, self.conv2, self.short) if c is not None]
 
-    def fwd(self, x, temb, training, res2, tape, drop_mask=None):
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
         a1, coef1 = self.bn1.fwd(x, training)
         tproj = self.temb.fwd(temb)
-        h1 = self.conv1.fwd(a1, temb=tproj)
+        h1 = self.conv1.fwd(a1, temb=tproj, want_stats=training)
         mask = None
         if training and self.spec.dropout > 0.0:
             mask = drop_mask if drop_mask is not None else self.eng.draw_dropout(h1.shape, self.spec.dropout)
         a2, coef2 = self.bn2.fwd(h1, training, mask)
         sc = self.short.fwd(x) if self.short is not None else x
-        y = self.conv2.fwd(a2, res=sc, res2=res2)
+        y = self.conv2.fwd(a2, res=sc, res2=res2, want_stats=want_stats)
         if tape is not None:
             tape.append((self, (x, a1, coef1, h1, a2, coef2, mask, temb)))
         return y
@@ -246,14 +270,12 @@ class _ResBlock:
         x, a1, coef1, h1, a2, coef2, mask, temb = saved
         e = self.eng
         # conv2 and shortcut share dy; their bias gradients are the same column sums of dy
-        part, nchunk, G = _chan_sums(e, dy, False)
-        call("vamd_sum_finalize", _ptr(part), nchunk, G, self.spec.cout, None, _ptr(self.conv2.gb), _stream())
         self.conv2.wgrad(dy, a2)
         da2 = self.conv2.dgrad(dy, a2.shape)
         dxs = dy
         if self.short is not None:
             self.short.gb.copy_(self.conv2.gb)
-            self.short.wgrad(dy, x)
+            self.short.wgrad(dy, x, bias=False)
             dxs = self.short.dgrad(dy, x.shape) if need_dx else None
         dh1 = self.bn2.bwd(da2, h1, coef2, mask)
         # d(projected temb)[b][c] = sum over pixels of dh1; conv1 bias gradient = its sum over b
@@ -261,7 +283,7 @@ class _ResBlock:
         dtproj = torch.empty((G, self.spec.cout), dtype=torch.float32, device=dy.device)
         call("vamd_sum_finalize", _ptr(part), nchunk, G, self.spec.cout, _ptr(dtproj), _ptr(self.conv1.gb), _stream())
         self.temb.bwd(temb, dtproj, dx=dtemb, accumulate=True)
-        self.conv1.wgrad(dh1, a1)
+        self.conv1.wgrad(dh1, a1, bias=False)
         da1 = self.conv1.dgrad(dh1, a1.shape)
         return self.bn1.bwd(da1, x, coef1, None, add=dxs, add2=extra, need_dx=need_dx)
 
@@ -298,7 +320,7 @@ class _AttnBlock:
         call("vamd_transpose", _ptr(t), _ptr(out), batch, R, Cc, ld, self.eng.dt, _stream())
         return out
 
-    def fwd(self, x, temb, training, res2, tape, drop_mask=None):
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
         B, H, W, Cc = x.shape
         S = H * W
         Sp = (S + 7) // 8 * 8
@@ -312,7 +334,7 @@ class _AttnBlock:
         vT = self._transpose_padded(v, B, S, Cc, Sp)                          # [B][C][Sp]
         o = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)             # o[s][c] = sum_t P[s][t] v[t][c]
         self._bmm_nt(P, vT, o, B, S, Cc, S, Sp, Sp, Cc, 1.0)
-        y = self.o.fwd(o, res=x, res2=res2)
+        y = self.o.fwd(o, res=x, res2=res2, want_stats=want_stats)
         if tape is not None:
             tape.append((self, (x, hn, coef, q, k, v, P, o)))
         return y
@@ -323,8 +345,6 @@ class _AttnBlock:
         B, H, W, Cc = x.shape
         S = H * W
         Sp = P.shape[2]
-        part, nchunk, G = _chan_sums(e, dy, False)
-        call("vamd_sum_finalize", _ptr(part), nchunk, G, Cc, None, _ptr(self.o.gb), _stream())
         self.o.wgrad(dy, o)
         do = self.o.dgrad(dy, o.shape)
         dP = torch.empty((B, S, Sp), dtype=torch.float32, device=dev)         # dP[s][t] = sum_c do[s][c] v[t][c]
@@ -340,8 +360,6 @@ class _AttnBlock:
         self._bmm_tn(dS, q, dk, B, S, Cc, S, Sp, Cc, Cc)
         dhn = None
         for conv, g in ((self.q, dq), (self.k, dk), (self.v, dv)):
-            part, nchunk, G = _chan_sums(e, g, False)
-            call("vamd_sum_finalize", _ptr(part), nchunk, G, Cc, None, _ptr(conv.gb), _stream())
             conv.wgrad(g, hn)
             dhn = conv.dgrad(g, hn.shape, add=dhn)
         return self.norm.bwd(dhn, x, coef, None, add=dy, add2=extra, need_dx=need_dx)
@@ -360,16 +378,14 @@ class _Resample:
             self.conv = _Conv(eng, p + ".layers.1", spec.cin, spec.cout, 3, up=True)
         self.convs = [self.conv]
 
-    def fwd(self, x, temb, training, res2, tape, drop_mask=None):
-        y = self.conv.fwd(x, res2=res2)
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
+        y = self.conv.fwd(x, res2=res2, want_stats=want_stats)
         if tape is not None:
             tape.append((self, (x,)))
         return y
 
     def bwd(self, saved, dy, extra, dtemb, need_dx=True):
         (x,) = saved
-        part, nchunk, G = _chan_sums(self.eng, dy, False)
-        call("vamd_sum_finalize", _ptr(part), nchunk, G, self.spec.cout, None, _ptr(self.conv.gb), _stream())
         self.conv.wgrad(dy, x)
         return self.conv.dgrad(dy, x.shape, add=extra)
 
@@ -383,6 +399,7 @@ class Engine:
             raise NotImplementedError("with_conv=False (AvgPool2d / bare Upsample resampling) has no HIP kernels yet")
         self.device = params[0][1].device
         self.plan, self.dtype, self.algo = plan, dtype, algo
+        self.stats_for: Dict[int, tuple] = {}      # output data_ptr -> (partial sums, parts) left by a conv epilogue
         self.dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}[dtype]
 
         # one flat fp32 arena for parameters and one for gradients; every nn.Parameter becomes a view
@@ -515,6 +532,7 @@ class Engine:
         """x: [B,H,W,3] compute dtype; t: [B] fp32 (the reference feeds noise_rate**2).
         Returns the NHWC prediction; if `tape` is a list it receives what backward needs."""
         self.refresh()
+        self.stats_for.clear()
         B = x.shape[0]
         drop_masks = drop_masks or {}
         emb = torch.empty((B, self.plan.ch), dtype=torch.float32, device=x.device)
@@ -534,7 +552,10 @@ class Engine:
             j = i + 1 - nd - nm                     # index of the up module consuming this output
             if 0 <= j < n_up and j < nd:
                 res2 = skips[nd - 1 - j]
-            h = layer.fwd(h, temb, training, res2, tape, drop_masks.get(layer.spec.prefix))
+            # a train-mode ResBlock next: its first BatchNorm takes its statistics from this layer's epilogue
+            nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
+            want = training and isinstance(nxt, _ResBlock)
+            h = layer.fwd(h, temb, training, res2, tape, drop_masks.get(layer.spec.prefix), want_stats=want)
             if self.debug_taps is not None:
                 self.debug_taps[layer.spec.prefix] = (h, res2)
             if i < nd:
@@ -554,8 +575,6 @@ class Engine:
         red = self.reducer
         if red is not None:
             red.begin()
-        part, nchunk, G = _chan_sums(self, dout, False)
-        call("vamd_sum_finalize", _ptr(part), nchunk, G, self.end.cout, None, _ptr(self.end.gb), _stream())
         self.end.wgrad(dout, h_end)
         g = self.end.dgrad(dout, h_end.shape)
         if red is not None:
