@@ -85,10 +85,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # one rank per GPU; VAMD_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path
+    backend = os.environ.get("VAMD_DIST_BACKEND", "nccl")
+    local_rank = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     rank = dist.get_rank() if world > 1 else 0
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)

@@ -1,0 +1,118 @@
+"""Two data-parallel ranks on ONE MI355X (both on cuda:0, gloo carrying the device tensors): the
+engine's backward issues the bucketed gradient all-reduce through GradReducer, FusedAdamW waits
+for it, buffers are broadcast from rank 0.  Checked against a single-process run of the same two
+per-rank batches: reduced gradients = mean of the per-rank gradients (fp32 compute, 1e-5), and
+both ranks hold identical parameters after two optimizer steps.  RCCL itself is exercised by
+`bench.py --gpus N` on a multi-GPU node; this test covers everything around the collective."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+import torch.distributed as dist            # noqa: E402
+import torch.multiprocessing as mp          # noqa: E402
+
+from conftest import load_golden, sub       # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _batch(cfg, B, rank, step):
+    g = torch.Generator().manual_seed(1000 + 10 * step + rank)
+    P = cfg["patch_size"]
+    return (torch.rand((B, 3, P, P), generator=g), torch.randn((B, 3, P, P), generator=g),
+            torch.rand((B, 1, 1, 1), generator=g))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import vision_amd
+    from vision_amd.parallel import DataParallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        t, cfg, B = load_golden("t1")
+        model = vision_amd.get_model("ddpm", cfg, compute_dtype="fp32").to(dev).train()
+        state = sub(t, "state0")
+        if rank == 1:                      # rank 1 starts from different weights: the broadcast must fix that
+            state = {k: (v + 0.25 if v.dtype.is_floating_point else v) for k, v in state.items()}
+        model.load_state_dict(state)
+        dp = DataParallel(model, bucket_bytes=64 << 10)          # several buckets even on the tiny model
+        assert len(dp.reducer.buckets) > 2
+        opt = model.configure_optimizers()[0][0]
+        eng = model._ensure_engine()
+        grads = []
+        for step in range(2):
+            x, eps, tt = (v.to(dev) for v in _batch(cfg, B, rank, step))
+            dp.broadcast_buffers()
+            loss = model.p_loss(x, noises=eps, diffusion_times=tt)
+            loss.backward()
+            dp.reducer.wait()
+            grads.append(eng.flat_g.clone().cpu())
+            opt.step()
+        torch.cuda.synchronize()
+        torch.save({"grads": grads, "params": eng.flat_p.cpu(), "bufs": eng.flat_b.cpu()},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process(tmp_path):
+    import vision_amd
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    # identical reduced gradients and parameters on both ranks
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b)
+    assert torch.equal(r0["params"], r1["params"])
+
+    # single process: per-rank gradients of the same batches, averaged by hand
+    dev = torch.device("cuda:0")
+    t, cfg, B = load_golden("t1")
+    model = vision_amd.get_model("ddpm", cfg, compute_dtype="fp32").to(dev).train()
+    model.load_state_dict(sub(t, "state0"))
+    eng = model._ensure_engine()
+    opt = model.configure_optimizers()[0][0]
+    bufs0 = eng.flat_b.clone()
+    for step in range(2):
+        per_rank = []
+        bufs_after_rank0 = None
+        for rank in range(world):
+            eng.flat_b.copy_(bufs0)                       # every rank starts the step from rank 0's buffers
+            x, eps, tt = (v.to(dev) for v in _batch(cfg, B, rank, step))
+            loss = model.p_loss(x, noises=eps, diffusion_times=tt)
+            loss.backward()
+            per_rank.append(eng.flat_g.clone())
+            if rank == 0:
+                bufs_after_rank0 = eng.flat_b.clone()
+        mean = (per_rank[0] + per_rank[1]) / 2
+        got = r0["grads"][step].to(dev)
+        err = ((got - mean).norm() / mean.norm()).item()
+        assert err < 1e-5, (step, err)
+        eng.flat_g.copy_(mean)
+        eng.flat_b.copy_(bufs_after_rank0)                # rank 0's statistics are what the next broadcast spreads
+        bufs0 = bufs_after_rank0.clone()
+        opt.step()
+    # AdamW's first steps move every parameter by ~lr * sign(g): parameters whose exact gradient is
+    # zero (their computed gradient is rounding noise that depends on summation order) may differ
+    # by up to 2 * lr per step; everything else agrees to fp32 rounding
+    diff = (r0["params"].to(dev) - eng.flat_p).abs()
+    assert float(diff.max()) <= 2 * 2 * cfg["learning_rate"] * 1.01
+    perr = (diff.norm() / eng.flat_p.norm()).item()
+    assert perr < 2e-3, perr
+    assert torch.allclose(r0["bufs"].to(dev), eng.flat_b, rtol=1e-5, atol=1e-6)

@@ -251,6 +251,7 @@ class _ResBlock:
         self.conv2 = _Conv(eng, p + ".block2.0.3", spec.cout, spec.cout, 3)
         self.short = _Conv(eng, p + ".layers.0", spec.cin, spec.cout, 1) if spec.cin != spec.cout else None
         self.convs = [c for c in (self.conv1, self.conv2, self.short) if c is not None]
+        self._gb_stale = False                   # conv1's bias gradient holds an eval-mode value
 
     def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
         a1, coef1 = self.bn1.fwd(x, training)
@@ -263,11 +264,11 @@ class _ResBlock:
         sc = self.short.fwd(x) if self.short is not None else x
         y = self.conv2.fwd(a2, res=sc, res2=res2, want_stats=want_stats)
         if tape is not None:
-            tape.append((self, (x, a1, coef1, h1, a2, coef2, mask, temb)))
+            tape.append((self, (x, a1, coef1, h1, a2, coef2, mask, temb, training)))
         return y
 
     def bwd(self, saved, dy, extra, dtemb, need_dx=True):
-        x, a1, coef1, h1, a2, coef2, mask, temb = saved
+        x, a1, coef1, h1, a2, coef2, mask, temb, training = saved
         e = self.eng
         # conv2 and shortcut share dy; their bias gradients are the same column sums of dy
         self.conv2.wgrad(dy, a2)
@@ -283,7 +284,12 @@ class _ResBlock:
         dtproj = torch.empty((G, self.spec.cout), dtype=torch.float32, device=dy.device)
         call("vamd_sum_finalize", _ptr(part), nchunk, G, self.spec.cout, _ptr(dtproj), _ptr(self.conv1.gb), _stream())
         self.temb.bwd(temb, dtproj, dx=dtemb, accumulate=True)
-        self.conv1.wgrad(dh1, a1, bias=False)
+        # conv1's bias feeds a train-mode BatchNorm, whose mean subtraction cancels it: the
+        # gradient is exactly zero (dh1 sums to zero over the batch) and is not computed
+        if training and self._gb_stale:
+            self.conv1.gb.zero_()
+        self._gb_stale = not training
+        self.conv1.wgrad(dh1, a1, bias=not training)
         da1 = self.conv1.dgrad(dh1, a1.shape)
         return self.bn1.bwd(da1, x, coef1, None, add=dxs, add2=extra, need_dx=need_dx)
 
