@@ -26,6 +26,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+T_START = time.perf_counter()
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X
 HBM_PEAK_GBS = 8000.0
 
@@ -79,8 +80,16 @@ def cpu_baseline(seconds_budget=25.0):
                       f"sampling 4 images x 2 steps took {samp:.1f} s = {4 * 2 / samp:.2f} image-steps/s"}
 
 
+def trace(msg):
+    if os.environ.get("VAMD_BENCH_TRACE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')} t={time.perf_counter() - T_START:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
+    if os.environ.get("VAMD_BENCH_TRACE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(45, exit=False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -96,6 +105,7 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
+    trace("process group up")
     import vision_amd
     from vision_amd.parallel import DataParallel
     from vision_amd.presets import get_preset
@@ -106,7 +116,9 @@ def main():
     P = cfg["patch_size"]
     torch.manual_seed(cfg["manual_seed"])
     model = vision_amd.get_model("ddpm", cfg, compute_dtype=args.dtype).to(dev).train()
+    trace("model on device")
     dp = DataParallel(model)
+    trace("parameters and buffers broadcast")
     eng = model._ensure_engine()
     opt = model.configure_optimizers()[0][0]
 
@@ -122,8 +134,10 @@ def main():
         opt.step()
         return loss
 
+    trace("model built")
     for i in range(args.warmup):
         step(i)
+        trace(f"warmup step {i} issued")
     model.train_losses.clear()
 
     def fence():
@@ -133,14 +147,17 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    trace("warmup done")
     ev_steps = args.steps if args.event_steps is None else min(args.event_steps, args.steps)
     prof = []                 # (kind, flops, start_event, end_event, shape) per MFMA conv launch
     t0 = time.perf_counter()
     for i in range(args.steps):
         eng.profile = prof if i < ev_steps else None
         loss = step(args.warmup + i)
+        trace(f"timed step {i} issued")
     host_elapsed = time.perf_counter() - t0          # launches issued; the device may still be running
     fence()
+    trace("timed steps done")
     elapsed = time.perf_counter() - t0
     eng.profile = None
     if world > 1:

@@ -17,6 +17,7 @@ passed the layer whose parameters start at `lo`, the slice is complete and its a
 issued asynchronously; the optimiser waits for all of them.  On a fully connected 8-GPU xGMI mesh
 a 25 MB bucket moves in ~0.2 ms, so the exchange hides behind the remaining backward kernels.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -52,6 +53,8 @@ class GradReducer:
         self._pending = []
         backend = dist.get_backend(group) if self.world > 1 else "none"
         self._use_avg = backend == "nccl"     # ReduceOp.AVG exists for nccl/RCCL only
+        # VAMD_DP_SERIAL=1: blocking collectives (no overlap with backward), for debugging
+        self._serial = os.environ.get("VAMD_DP_SERIAL", "0") == "1"
 
     def begin(self):
         self._next = 0
@@ -74,6 +77,10 @@ class GradReducer:
         # async_op: the collective runs on the backend's own stream after everything already
         # queued on the current stream (the kernels that produced this slice), while later
         # backward kernels keep the compute stream busy
+        if self._serial:
+            dist.all_reduce(view, op=op, group=self.group)
+            self._pending.append((None, view))
+            return
         work = dist.all_reduce(view, op=op, group=self.group, async_op=True)
         self._pending.append((work, view))
 
@@ -82,7 +89,8 @@ class GradReducer:
         if self._next < len(self.buckets):
             self.finish()
         for work, view in self._pending:
-            work.wait()
+            if work is not None:
+                work.wait()
             if not self._use_avg:
                 view.mul_(1.0 / self.world)
         self._pending = []
