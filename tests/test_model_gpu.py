@@ -11,8 +11,9 @@ implementation can reproduce:
 `test_backward_exact_inputs` therefore feeds the network the reference's own x_t and n^2 bits
 (through forward(x, t)) and compares every parameter gradient with the exact gradient of the same
 function, evaluated in fp64 by the oracle (relative Frobenius norm per tensor):
-  fp32 compute: error <= max(2e-5, 4 x the error of the reference's own fp32 gradient)
-  bf16 compute: error <= max(6e-2, 3 x the error of a bf16-autocast run of the reference
+  fp32 compute: error <= max(2e-5, 4 x the error of the reference's own fp32 gradient), per tensor
+                and (with 1e-5 as the floor) over all parameters together
+  bf16 compute: error <= max(8e-2, 3 x the error of a bf16-autocast run of the reference
                 arithmetic), and <= max(8e-2, 2 x that figure) over all parameters together.
 `test_loss_grads_bnstats` runs the whole training objective p_loss (schedule evaluated on the
 device) and checks the loss (1e-5 / 1e-2 relative), the BatchNorm statistics and the gradients
@@ -118,7 +119,7 @@ def exact_gradients(name, g, cfg):
         ebf = {k: rel(gbf[k], g64[k]) for k in ref if k not in zero}
         keys = sorted(e32)
         cat = lambda d: torch.cat([d[k].double().flatten() for k in keys])
-        _TRUTH[name] = (pred64, g64, e32, ebf, rel(cat(gbf), cat(g64)))
+        _TRUTH[name] = (pred64, g64, e32, ebf, rel(cat(gbf), cat(g64)), rel(cat(ref), cat(g64)))
     return _TRUTH[name]
 
 
@@ -130,7 +131,7 @@ def test_backward_exact_inputs(golden, mode):
     """forward(x, t) on the reference's x_t / n^2 bits, L1 against eps, every gradient vs exact."""
     name, g, cfg, B = golden
     dtype = MODES[mode][0]
-    pred64, g64, e32, ebf, ebf_all = exact_gradients(name, g, cfg)
+    pred64, g64, e32, ebf, ebf_all, e32_all = exact_gradients(name, g, cfg)
     m = make_model(cfg, sub(g, "state0"), mode).train()
     m.set_dropout_masks(masks_for(g, cfg, dtype))
     out = m(g["x_t"].to(DEV), (g["sched_n"] ** 2).to(DEV))
@@ -148,13 +149,15 @@ def test_backward_exact_inputs(golden, mode):
                 failures.append((k, "nonzero", grads[k].abs().max().item()))
             continue
         e = rel(grads[k], g64[k])
-        bound = max(2e-5, 4 * e32[k]) if dtype == torch.float32 else max(6e-2, 3 * ebf[k])
+        bound = max(2e-5, 4 * e32[k]) if dtype == torch.float32 else max(8e-2, 3 * ebf[k])
         if e > bound:
             failures.append((k, e, bound))
     assert not failures, failures
     keys = sorted(e32)
     e_all = rel(_cat(grads, keys), _cat(g64, keys))
-    assert e_all < (1e-5 if dtype == torch.float32 else max(8e-2, 2 * ebf_all)), e_all
+    # a float32 forward may round a few pred - eps differences to the other side of zero than the
+    # exact one does (the reference's own fp32 run does): allow what the reference itself shows
+    assert e_all < (max(1e-5, 4 * e32_all) if dtype == torch.float32 else max(8e-2, 2 * ebf_all)), e_all
 
 
 def test_loss_grads_bnstats(golden, mode):
@@ -162,7 +165,7 @@ def test_loss_grads_bnstats(golden, mode):
     name, g, cfg, B = golden
     dtype = MODES[mode][0]
     tol = TOL[dtype]
-    _, g64, e32, ebf, ebf_all = exact_gradients(name, g, cfg)
+    _, g64, e32, ebf, ebf_all, _e32_all = exact_gradients(name, g, cfg)
     m = make_model(cfg, sub(g, "state0"), mode).train()
     m.set_dropout_masks(masks_for(g, cfg, dtype))
     loss = m.p_loss(g["x0"].to(DEV), g["eps"].to(DEV), g["t"].to(DEV))
