@@ -701,6 +701,15 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
 //   AN = 128, BF = 128: waves 2 x 2, each 64 n x 64 f                       (Cout >= 128, attention)
 //   AN =  64, BF = 192: waves 1 x 4, each 64 n x 48 f  (9*Cin is a multiple of 192 for Cin % 64 == 0)
 // Grid: (n tiles * f tiles, split-K slices); partial tiles are combined with fp32 atomics.
+// ds_read_b64_tr_b16 of the 4 rows x 16 columns block this lane's 16-lane group addresses; the
+// result is valid only after a later s_waitcnt lgkmcnt (the compiler does not know this is an LDS read)
+template <int OFF> __device__ __forceinline__ s16x4_t lds_read_tr16(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "immediate offset of a DS instruction");
+    s16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
 template <int ROWB> __device__ __forceinline__ int tn_swizzle(int row) {
     // XOR applied to the 16-byte piece index of a row so that the 8 rows x 32 bytes that 32 lanes
     // fetch with one transposing read fall on 8 different bank groups
@@ -729,7 +738,11 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int bid = blockIdx.x;
+    // workgroups that share an XCD (and its L2) take consecutive (slice, tile) pairs: the tiles of
+    // one pixel slice read the same dY / X rows
+    const int n_ft = n_tiles * f_tiles;
+    const int rid = xcd_remap(blockIdx.x, gridDim.x);
+    const int slice = rid / n_ft, bid = rid - slice * n_ft;
     const int nt = bid / f_tiles, ft = bid - nt * f_tiles;
     const int n0 = nt * AN, f0 = ft * BF;
     dy += (int64_t)blockIdx.z * strideA;
@@ -740,7 +753,7 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     // advances by KP per K-step, so its (image, row, column) and its dY offset are carried along
     // with adds and single-wrap compares; nothing is divided inside the loop.
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const int step0 = blockIdx.y * steps_per_slice;
+    const int step0 = slice * steps_per_slice;
     const int total_steps = (gp.M + KP - 1) / KP;
     int step1 = step0 + steps_per_slice;
     if (step1 > total_steps) step1 = total_steps;
@@ -826,36 +839,62 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // bf16: one 16x16x32 MFMA k-step covers 32 pixels; lane l supplies row k0 + ((l&15)>>2),
-    // columns c0 + 4*(l&3) to the transposing read
-    auto read_frags = [&](int buf, int ks, bf16x8_t (&a)[4], bf16x8_t (&b)[NJ]) {
-        const unsigned char* sa = smem + buf * STAGE;
-        const unsigned char* sb = sa + TILE_A;
+    // columns c0 + 4*(l&3) to the transposing read.  The reads are issued as inline assembly: the
+    // compiler orders its own ds_read_b64_tr_b16 after every outstanding direct-to-LDS load
+    // (s_waitcnt vmcnt(0)), which would serialise the prefetch of the next K-step behind them.
+    // Each read's address is a per-lane constant plus immediates for (k-step half, row group).
+    uint32_t a_addr[4], b_addr[NJ];
+    if constexpr (BF16) {
         const int q = (lane & 15) >> 2, p = lane & 3, g = lane >> 4;
+        const int row0 = g * 8 + q;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)LPTR(smem);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int row = ks * 32 + g * 8 + h * 4 + q;
-            const int swa = tn_swizzle<ROWB_A>(row), swb = tn_swizzle<ROWB_B>(row);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = wm * 64 + i * 16 + p * 4;            // element column
-                const int pc = (col >> 3) ^ swa;                     // physical 16-byte piece
-                const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(sa + row * ROWB_A + pc * 16 + (col & 7) * 2));
-                const bf16x4_t fa = __builtin_bit_cast(bf16x4_t, va);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a[i][h * 4 + e] = fa[e];
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int colb = wn * (16 * NJ) + j * 16 + p * 4;
-                const int pcb = (colb >> 3) ^ swb;
-                const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(sb + row * ROWB_B + pcb * 16 + (colb & 7) * 2));
-                const bf16x4_t fb = __builtin_bit_cast(bf16x4_t, vb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) b[j][h * 4 + e] = fb[e];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int col = wm * 64 + i * 16 + p * 4;
+            a_addr[i] = lds0 + row0 * ROWB_A + ((col >> 3) ^ tn_swizzle<ROWB_A>(row0)) * 16 + (col & 7) * 2;
         }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = wn * (16 * NJ) + j * 16 + p * 4;
+            b_addr[j] = lds0 + TILE_A + row0 * ROWB_B + ((col >> 3) ^ tn_swizzle<ROWB_B>(row0)) * 16 + (col & 7) * 2;
+        }
+    }
+    // raw[..][h]: rows +0..3 (h = 0) and +4..7 (h = 1) of a fragment; valid only after frag_wait
+    auto read_frags = [&](int buf, auto ks_c, s16x4_t (&ra)[4][2], s16x4_t (&rb)[NJ][2]) {
+        constexpr int ks = decltype(ks_c)::value;
+        const uint32_t boff = buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i][0] = lds_read_tr16<ks * 32 * ROWB_A>(a_addr[i] + boff);
+            ra[i][1] = lds_read_tr16<ks * 32 * ROWB_A + 4 * ROWB_A>(a_addr[i] + boff);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            rb[j][0] = lds_read_tr16<ks * 32 * ROWB_B>(b_addr[j] + boff);
+            rb[j][1] = lds_read_tr16<ks * 32 * ROWB_B + 4 * ROWB_B>(b_addr[j] + boff);
+        }
+    };
+    auto frag_wait = [&](s16x4_t (&ra)[4][2], s16x4_t (&rb)[NJ][2], bf16x8_t (&a)[4], bf16x8_t (&b)[NJ]) {
+        // every later use of the raw registers depends on this wait
+        if constexpr (NJ == 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
+                           "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1]));
+        } else {
+            static_assert(NJ == 3 || NJ == 4, "fragment wait is written for 3 or 4 column tiles");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
+                           "+v"(rb[2][0]), "+v"(rb[2][1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(ra[i][0], ra[i][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            b[j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(rb[j][0], rb[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
     };
     auto mma = [&](const bf16x8_t (&a)[4], const bf16x8_t (&b)[NJ]) {
 #pragma unroll
@@ -900,10 +939,13 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     };
     auto compute = [&](int buf) {
         if constexpr (BF16) {
+            s16x4_t ra[4][2], rb[NJ][2];
             bf16x8_t a[4], b[NJ];
-            read_frags(buf, 0, a, b);
+            read_frags(buf, std::integral_constant<int, 0>{}, ra, rb);
+            frag_wait(ra, rb, a, b);
             mma(a, b);
-            read_frags(buf, 1, a, b);
+            read_frags(buf, std::integral_constant<int, 1>{}, ra, rb);
+            frag_wait(ra, rb, a, b);
             mma(a, b);
         } else {
             compute_f32(buf);
@@ -920,12 +962,15 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
         for (int t = step0; t + 1 < step1; ++t) {
             const int cur = (t - step0) & 1, nxt = cur ^ 1;
             if constexpr (BF16) {
+                s16x4_t ra[4][2], rb[NJ][2];
                 bf16x8_t a[4], b[NJ];
-                read_frags(cur, 0, a, b);
+                read_frags(cur, std::integral_constant<int, 0>{}, ra, rb);
                 stage_a(nxt);
+                frag_wait(ra, rb, a, b);
                 mma(a, b);
-                read_frags(cur, 1, a, b);
+                read_frags(cur, std::integral_constant<int, 1>{}, ra, rb);
                 stage_b(nxt);
+                frag_wait(ra, rb, a, b);
                 mma(a, b);
             } else {
                 stage_a(nxt);
@@ -1229,15 +1274,16 @@ static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int
     int slices = 1;
     if (out_mode == 0) {
         // enough workgroups to fill 256 CUs x 2, but at least 8 K-steps per slice
+        // at most 1024 workgroups (two per CU at once): a few more would cost a whole extra round
         const int tiles = n_tiles * f_tiles * batch;
-        slices = (1024 + tiles - 1) / tiles;
+        slices = 1024 / tiles;
         const int max_slices = (total_steps + 7) / 8;
         if (slices > max_slices) slices = max_slices;
         if (slices < 1) slices = 1;
     }
     const int steps_per = (total_steps + slices - 1) / slices;
     slices = (total_steps + steps_per - 1) / steps_per;
-    dim3 grid(n_tiles * f_tiles, slices, batch);
+    dim3 grid(n_tiles * f_tiles * slices, 1, batch);
     hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
                        f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias);
     VAMD_LAUNCH_OK("conv_tn_mfma");
