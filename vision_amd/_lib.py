@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvision_amd.so")
+# VAMD_LIB: another build of the same library (side-by-side kernel experiments)
+LIB_PATH = os.environ.get("VAMD_LIB") or os.path.join(_HERE, "lib", "libvision_amd.so")
 
 F32, BF16 = 0, 1
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA, ALGO_THIN = 0, 1, 2, 3

@@ -968,12 +968,14 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
             if constexpr (BF16) {
                 s16x4_t ra[4][2], rb[NJ][2];
                 bf16x8_t a[4], b[NJ];
+                // measured: both halves of the next stage issued before the first MFMA half beat
+                // issuing the second half later
                 read_frags(cur, std::integral_constant<int, 0>{}, ra, rb);
                 stage_a(nxt);
+                stage_b(nxt);
                 frag_wait(ra, rb, a, b);
                 mma(a, b);
                 read_frags(cur, std::integral_constant<int, 1>{}, ra, rb);
-                stage_b(nxt);
                 frag_wait(ra, rb, a, b);
                 mma(a, b);
             } else {
