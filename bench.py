@@ -10,7 +10,8 @@ batch 64 per GPU, 224x224, bf16 compute.  N > 1 is weak scaling (64 images per G
 
 Rank 0 prints ONE JSON line: metric value = training images/s over all GPUs, plus
   roofline     - the MFMA implicit-GEMM kernel (forward + input-gradient launches): algorithmic
-                 FLOPs / device time measured with HIP events around every launch;
+                 FLOPs / device time, from HIP events the library records on the launch stream
+                 right before and after every launch of that kernel in the timed steps;
   cpu_baseline - the oracle's CPU restatement timed on a bounded sample of configs[0]
                  (flowers model, batch 8), N = 1 only.
 """
@@ -42,8 +43,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--sample-steps", type=int, default=10)
-    ap.add_argument("--event-steps", type=int, default=None,
-                    help="timed steps whose MFMA conv launches are bracketed by HIP events (default: all)")
     return ap.parse_args()
 
 
@@ -125,6 +124,7 @@ def main():
     trace("process group up")
     import vision_amd
     from vision_amd.parallel import DataParallel
+    from vision_amd._lib import lib
     from vision_amd.presets import get_preset
 
     preset = get_preset(args.preset)
@@ -165,11 +165,14 @@ def main():
 
     fence()
     trace("warmup done")
-    ev_steps = args.steps if args.event_steps is None else min(args.event_steps, args.steps)
-    prof = []                 # (kind, flops, start_event, end_event, shape) per MFMA conv launch
+    # per-launch HIP events inside the library, on the launch stream, around every MFMA conv kernel;
+    # VAMD_BENCH_LAYERS=1 adds per-call events in the engine for a per-layer table
+    layers = bool(os.environ.get("VAMD_BENCH_LAYERS"))
+    prof = []                 # (kind, flops, start_event, end_event, shape) per MFMA conv call
+    lib.vamd_launch_timing(1)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.profile = prof if i < ev_steps else None
+        eng.profile = prof if layers else None
         loss = step(args.warmup + i)
         trace(f"timed step {i} issued")
     host_elapsed = time.perf_counter() - t0          # launches issued; the device may still be running
@@ -177,6 +180,7 @@ def main():
     trace("timed steps done")
     elapsed = time.perf_counter() - t0
     eng.profile = None
+    lib.vamd_launch_timing(0)
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -184,36 +188,43 @@ def main():
     ips = world * B * args.steps / elapsed
     final_loss = float(loss.detach())
 
-    # roofline of the dominant kernel: MFMA implicit-GEMM "NT" (forward + input gradient)
-    kinds = {}
-    per_shape = {}
-    for kind, flops, e0, e1, shape in prof:
-        ms = e0.elapsed_time(e1)
-        f0, t0_, n0 = per_shape.get(shape, (0.0, 0.0, 0))
-        per_shape[shape] = (f0 + flops, t0_ + ms, n0 + 1)
-        f, t, n = kinds.get(kind, (0.0, 0.0, 0))
-        kinds[kind] = (f + flops, t + ms, n + 1)
+    # roofline of the dominant kernel: persistent MFMA implicit-GEMM (forward + input gradient)
+    import ctypes
+
+    def timed(kind):
+        ms, fl = ctypes.c_double(), ctypes.c_double()
+        n = lib.vamd_launch_timing_read(kind, ctypes.byref(ms), ctypes.byref(fl))
+        if n < 0:
+            raise RuntimeError(lib.vamd_last_error().decode())
+        return fl.value, ms.value, n
+
     roof = None
-    if "nt" in kinds:
-        f, t, n = kinds["nt"]
+    extra = {}
+    conv_ms = 0.0
+    f, t, n = timed(0)
+    if n:
+        conv_ms += t
         ach = f / (t * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "conv_ntp_mfma_kernel<bf16> (persistent implicit-GEMM, forward + input gradient)",
                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                 "traffic": measured_traffic("conv_ntp_mfma_kernel") if args.preset == "butterfly" and B == 64 else None,
                 "traffic_unit": "HBM bytes per launch (PMC pass of the same command, profiles/r1_pmc_tcc_traffic.csv)",
-                "launches": n, "avg_launch_ms": round(t / n, 4), "flops_per_launch": f / n}
-    extra = {}
-    if "tn" in kinds:
-        f, t, n = kinds["tn"]
+                "launches": n, "avg_launch_ms": round(t / n, 5), "flops_per_launch": round(f / n)}
+    f, t, n = timed(1)
+    if n:
+        conv_ms += t
         extra["wgrad_kernel"] = {"kernel": "conv_tn_mfma_kernel<bf16> (weight gradient)", "achieved_tflops": round(f / (t * 1e-3) / 1e12, 1),
-                                 "launches": n, "avg_launch_ms": round(t / n, 4)}
-    if os.environ.get("VAMD_BENCH_LAYERS") and rank == 0:
+                                 "launches": n, "avg_launch_ms": round(t / n, 5)}
+    if layers and rank == 0:
+        per_shape = {}
+        for kind, flops, e0, e1, shape in prof:
+            f0, t0_, n0 = per_shape.get(shape, (0.0, 0.0, 0))
+            per_shape[shape] = (f0 + flops, t0_ + e0.elapsed_time(e1), n0 + 1)
         for shape, (f, t, n) in sorted(per_shape.items(), key=lambda kv: -kv[1][1]):
             print("layer %-52s calls %3d  %7.3f ms/call  %7.1f TFLOP/s  %5.1f%% of MFMA conv time" % (
                 str(shape), n, t / n, f / (t * 1e-3) / 1e12, 100 * t / sum(v[1] for v in per_shape.values())), file=sys.stderr)
-    conv_ms = sum(v[1] for v in kinds.values()) / max(ev_steps, 1)
-    extra["mfma_conv_ms_per_step"] = round(conv_ms, 3)
+    extra["mfma_conv_ms_per_step"] = round(conv_ms / args.steps, 3)
     extra["host_issue_ms_per_step"] = round(1e3 * host_elapsed / args.steps, 3)
 
     sampling = None

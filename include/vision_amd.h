@@ -34,6 +34,15 @@ const char* vamd_last_error(void);
 /* Library / ABI version, and whether the MFMA path is compiled in. */
 int vamd_version(void);
 
+/* Benchmark aid, no counterpart in the reference.  vamd_launch_timing(1) makes the MFMA
+ * convolution launchers record a HIP event pair around every kernel launch (on the stream of the
+ * launch) and forgets earlier records; vamd_launch_timing(0) stops recording.
+ * vamd_launch_timing_read waits for the recorded launches of `kind` (0: forward / input-gradient
+ * kernel, 1: weight-gradient kernel) to finish - the one call of this library that blocks - and
+ * returns their number, summed duration in ms and summed algorithmic FLOPs (2*M*N*K each). */
+int vamd_launch_timing(int enable);
+long vamd_launch_timing_read(int kind, double* total_ms, double* total_flops);
+
 /* ------------------------------------------------------------------ convolution
  * One descriptor for nn.Conv2d 3x3 pad 1 stride 1|2, 1x1 pad 0, and "nearest 2x upsample then
  * 3x3 conv" (upsample = 1).  H, W are the stored input extents (before upsampling). */

@@ -42,6 +42,8 @@ _d = C.POINTER(ConvDesc)
 SIGNATURES = {
     "vamd_last_error": (C.c_char_p, []),
     "vamd_version": (_i, []),
+    "vamd_launch_timing": (_i, [_i]),
+    "vamd_launch_timing_read": (C.c_long, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vamd_conv2d_fwd": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vamd_conv2d_fwd_stats": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vamd_conv2d_stats_parts": (_i, [_d]),

@@ -39,6 +39,18 @@ int fail(int code, const char* fmt, ...);
         }                                                                 \
     } while (0)
 
+// Launch timing (vamd_launch_timing): while switched on, a TimedLaunch on the stack of a launcher
+// records one HIP event right before and one right after the kernel launch it brackets.
+int timed_launch_begin(int kind, double flops, hipStream_t st);     // slot index or -1 when off
+void timed_launch_end(int slot, hipStream_t st);
+struct TimedLaunch {
+    int slot;
+    hipStream_t st;
+    TimedLaunch(int kind, double flops, hipStream_t s) : slot(timed_launch_begin(kind, flops, s)), st(s) {}
+    ~TimedLaunch() { if (slot >= 0) timed_launch_end(slot, st); }
+};
+enum { TIMED_NT = 0, TIMED_TN = 1 };
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 static inline int grid_for(int64_t work_items, int block, int max_blocks = 4096) {

@@ -1106,6 +1106,7 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
     }
     const int row_tiles = m_tiles * batch;
     const int groups = ntp_row_groups(row_tiles, n_tiles, ntp_per_cu(BN));
+    TimedLaunch timed(TIMED_NT, 2.0 * gp.M * N * gp.Ktot * batch, st);
     if (ep.stats)
         hipLaunchKernelGGL((conv_ntp_mfma_kernel<T, BN, UP, true>), dim3(groups * n_tiles), dim3(256), LDS_PIPE, st, gp, x,
                            w, N, ldw, ldc, ep, y, m_tiles, n_tiles, row_tiles, sA, sB, sC);
@@ -1290,6 +1291,7 @@ static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int
     const int steps_per = (total_steps + slices - 1) / slices;
     slices = (total_steps + steps_per - 1) / steps_per;
     dim3 grid(n_tiles * f_tiles * slices, 1, batch);
+    TimedLaunch timed(TIMED_TN, 2.0 * gp.M * N * gp.Ktot * batch, st);
     hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
                        f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias);
     VAMD_LAUNCH_OK("conv_tn_mfma");

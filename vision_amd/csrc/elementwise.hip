@@ -2,9 +2,39 @@
 // layout converters, transpose, row softmax, time-embedding path, AdamW, weight repacking.
 #include "common.h"
 
+#include <mutex>
+#include <vector>
+
 namespace vamd {
 
 static thread_local char g_err[512] = "";
+
+// ---- launch timing ----------------------------------------------------------------------------
+struct TimedSlot { hipEvent_t e0, e1; int kind; double flops; };
+static std::mutex g_timed_mu;
+static std::vector<TimedSlot> g_timed;       // events are created once and reused
+static size_t g_timed_used = 0;
+static bool g_timed_on = false;
+
+int timed_launch_begin(int kind, double flops, hipStream_t st) {
+    if (!g_timed_on) return -1;
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    if (g_timed_used == g_timed.size()) {
+        TimedSlot s{};
+        if (hipEventCreate(&s.e0) != hipSuccess || hipEventCreate(&s.e1) != hipSuccess) return -1;
+        g_timed.push_back(s);
+    }
+    TimedSlot& s = g_timed[g_timed_used];
+    s.kind = kind;
+    s.flops = flops;
+    if (hipEventRecord(s.e0, st) != hipSuccess) return -1;
+    return (int)g_timed_used++;
+}
+
+void timed_launch_end(int slot, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    (void)hipEventRecord(g_timed[slot].e1, st);
+}
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -382,6 +412,33 @@ extern "C" {
 
 const char* vamd_last_error(void) { return g_err; }
 int vamd_version(void) { return 1; }
+
+int vamd_launch_timing(int enable) {
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    g_timed_on = enable != 0;
+    if (g_timed_on) g_timed_used = 0;
+    return 0;
+}
+
+long vamd_launch_timing_read(int kind, double* total_ms, double* total_flops) {
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    double ms = 0.0, fl = 0.0;
+    long n = 0;
+    for (size_t i = 0; i < g_timed_used; ++i) {
+        const TimedSlot& s = g_timed[i];
+        if (s.kind != kind) continue;
+        hipError_t e = hipEventSynchronize(s.e1);
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, s.e0, s.e1);
+        if (e != hipSuccess) return -(long)fail((int)e, "vamd_launch_timing_read: %s", hipGetErrorString(e));
+        ms += t;
+        fl += s.flops;
+        ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    return n;
+}
 
 int vamd_schedule(const float* t, float* n, float* s, float* n2, int B, void* stream) {
     VAMD_REQUIRE(t && n && s && n2 && B > 0, "vamd_schedule: null pointer or B <= 0");
