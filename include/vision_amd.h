@@ -105,6 +105,18 @@ int vamd_conv2d_uses_mfma(const vamd_conv_desc* d, int pass);
  * w_dgrad [Cin][k][k][Cout] flipped, both in `dtype`. */
 int vamd_repack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin,
                        int ksize, int dtype, void* stream);
+/* The same for every convolution of a model in ONE launch (the weight refresh after an optimiser
+ * step, models/ddpm.py:339-352 -> next forward).  `items` is an array of n entries in DEVICE
+ * memory; entry i covers blocks [first_block, first_block + ceil(Cout*Cin*k*k / 1024)), entries in
+ * ascending first_block order starting at 0; total_blocks = the sum of the counts. */
+typedef struct vamd_repack_item {
+    const float* w;        /* fp32 [Cout][Cin][k][k] */
+    void* w_fwd;           /* [Cout][k][k][Cin] in dtype */
+    void* w_dgrad;         /* [Cin][k][k][Cout] flipped, or NULL */
+    long long first_block;
+    int Cout, Cin, ksize, reserved;
+} vamd_repack_item;
+int vamd_repack_weights(const vamd_repack_item* items, int n, long long total_blocks, int dtype, void* stream);
 /* fp32 [Cout][k][k][Cin] -> fp32 [Cout][Cin][k][k] (gradient back to torch layout). */
 int vamd_unpack_wgrad(const float* dw_krsc, float* dw_oihw, int Cout, int Cin, int ksize,
                       void* stream);

@@ -84,6 +84,9 @@ CONV_CASES = [
     (2, 16, 16, 3, 32, 3, 1, 0),
     (2, 16, 16, 32, 3, 3, 1, 0),
     (2, 8, 8, 3, 3, 3, 1, 0),
+    (2, 10, 24, 3, 3, 3, 1, 0),
+    (2, 9, 12, 3, 3, 3, 1, 0),
+    (3, 5, 40, 3, 3, 1, 1, 0),
     (2, 8, 8, 3, 32, 1, 1, 0),
     (2, 8, 8, 3, 3, 1, 1, 0),
     (3, 37, 29, 3, 64, 3, 1, 0),

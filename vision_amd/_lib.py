@@ -28,6 +28,11 @@ class ConvDesc(C.Structure):
                 ("B", "H", "W", "Cin", "Cout", "ksize", "stride", "pad", "upsample", "dtype", "algo")]
 
 
+class RepackItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p), ("first_block", C.c_longlong),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("reserved", C.c_int32)]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build the HIP extension first (python vision_amd/build_ext.py). "
@@ -54,6 +59,7 @@ SIGNATURES = {
     "vamd_conv2d_wgrad_workspace": (_z, [_d]),
     "vamd_conv2d_uses_mfma": (_i, [_d, _i]),
     "vamd_repack_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vamd_repack_weights": (_i, [_p, _i, C.c_longlong, _i, _p]),
     "vamd_unpack_wgrad": (_i, [_p, _p, _i, _i, _i, _p]),
     "vamd_stats_chunks": (_i, [_l, _i]),
     "vamd_chan_stats": (_i, [_p, _p, _i, _l, _i, _i, _p]),

@@ -423,6 +423,178 @@ __global__ void tiny_wgrad_reduce_kernel(ConvGeom g, const float* __restrict__ s
     if (co < g.Cout && c < g.Cin) dw[((int64_t)co * K * K + tap) * g.Cin + c] = (float)sum;
 }
 
+
+// ------------------------------------------------------------------------------------ tiny33
+// Both sides are the 3-channel image (3 -> 3, the second conv of the last block and the End conv):
+// 6 bytes per pixel, so a thread takes 8 consecutive pixels of one image row (48 bytes in bf16 =
+// three 16-byte pieces, W % 8 == 0) plus the pixel left and right of them for a 3x3 filter, and
+// keeps the whole 3 x K x K x 3 filter in registers.  Grid-stride over the 8-pixel groups.
+template <typename T, int K>
+__device__ __forceinline__ void tiny33_load_row(const T* __restrict__ base, int64_t pix0, int w0, int W, bool ok,
+                                                float (&v)[8 + K - 1][3]) {
+    constexpr int VEC = Vec16<T>::N, NV = 24 / VEC, HALO = K / 2;
+#pragma unroll
+    for (int i = 0; i < 8 + K - 1; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[i][c] = 0.f;
+    if (!ok) return;
+    const T* p = base + pix0 * 3;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const Vec16<T> q = *reinterpret_cast<const Vec16<T>*>(p + i * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[HALO + (i * VEC + e) / 3][(i * VEC + e) % 3] = to_f(q.v[e]);
+    }
+    if (K == 3) {
+        if (w0 > 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[0][c] = to_f(p[c - 3]);
+        }
+        if (w0 + 8 < W) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[8 + K - 2][c] = to_f(p[24 + c]);
+        }
+    }
+}
+
+template <typename T, int K>
+__global__ void __launch_bounds__(256)
+tiny33_fwd_kernel(ConvGeom g, const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+                  const float* __restrict__ temb, const T* __restrict__ res, const T* __restrict__ res2,
+                  T* __restrict__ y) {
+    constexpr int VEC = Vec16<T>::N, NV = 24 / VEC, NW = 3 * K * K * 3;
+    __shared__ float ws[NW + 3];
+    for (int i = threadIdx.x; i < NW + 3; i += 256) ws[i] = i < NW ? to_f(w[i]) : (bias ? bias[i - NW] : 0.f);
+    __syncthreads();
+    float bo[3];                       // the filter stays in LDS: every lane reads the same word (broadcast)
+#pragma unroll
+    for (int o = 0; o < 3; ++o) bo[o] = ws[NW + o];
+    const int64_t groups = g.M / 8;
+    const int wg = g.W / 8;
+    for (int64_t grp = blockIdx.x * 256ll + threadIdx.x; grp < groups; grp += (int64_t)gridDim.x * 256) {
+        const int w0 = (int)(grp % wg) * 8;
+        const int64_t rowi = grp / wg;                     // b * H + h
+        const int h = (int)(rowi % g.H);
+        float acc[8][3];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) acc[p][o] = bo[o];
+#pragma unroll 1                       // one filter row at a time: 30 inputs + 27 filter words live, no spills
+        for (int r = 0; r < K; ++r) {
+            const int hi = h + r - K / 2;
+            float v[8 + K - 1][3];
+            tiny33_load_row<T, K>(x, (rowi + r - K / 2) * g.W + w0, w0, g.W, (unsigned)hi < (unsigned)g.H, v);
+#pragma unroll
+            for (int sx = 0; sx < K; ++sx)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        const float wv = ws[((o * K + r) * K + sx) * 3 + c];
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) acc[p][o] = fmaf(v[p + sx][c], wv, acc[p][o]);
+                    }
+        }
+        const int64_t e0 = grp * 24;
+        if (temb) {
+            const int64_t b = rowi / g.H;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float tv = temb[b * 3 + o];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) acc[p][o] += tv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            Vec16<T> out;
+            Vec16<T> r1, r2;
+            if (res) r1 = *reinterpret_cast<const Vec16<T>*>(res + e0 + i * VEC);
+            if (res2) r2 = *reinterpret_cast<const Vec16<T>*>(res2 + e0 + i * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float a = acc[(i * VEC + e) / 3][(i * VEC + e) % 3];
+                if (res) a += to_f(r1.v[e]);
+                if (res2) a += to_f(r2.v[e]);
+                out.v[e] = from_f<T>(a);
+            }
+            *reinterpret_cast<Vec16<T>*>(y + e0 + i * VEC) = out;
+        }
+    }
+}
+
+// weight gradient of the same layer: dw[o][r][s][c] = sum_p dy[p][o] * x[p + (r, s)][c]; every thread
+// keeps all 9 * K * K sums, a block writes one partial row to the slab.
+template <typename T, int K>
+__global__ void __launch_bounds__(256)
+tiny33_wgrad_kernel(ConvGeom g, const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ slab) {
+    constexpr int VEC = Vec16<T>::N, NV = 24 / VEC, NW = 3 * K * K * 3;
+    __shared__ float red[4][NW];
+    float acc[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) acc[i] = 0.f;
+    const int64_t groups = g.M / 8;
+    const int wg = g.W / 8;
+    for (int64_t grp = blockIdx.x * 256ll + threadIdx.x; grp < groups; grp += (int64_t)gridDim.x * 256) {
+        const int w0 = (int)(grp % wg) * 8;
+        const int64_t rowi = grp / wg;
+        const int h = (int)(rowi % g.H);
+        float d[8][3];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const Vec16<T> q = *reinterpret_cast<const Vec16<T>*>(dy + grp * 24 + i * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[(i * VEC + e) / 3][(i * VEC + e) % 3] = to_f(q.v[e]);
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int hi = h + r - K / 2;
+            float v[8 + K - 1][3];
+            tiny33_load_row<T, K>(x, (rowi + r - K / 2) * g.W + w0, w0, g.W, (unsigned)hi < (unsigned)g.H, v);
+#pragma unroll
+            for (int sx = 0; sx < K; ++sx)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        float a = acc[((o * K + r) * K + sx) * 3 + c];
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) a = fmaf(d[p][o], v[p + sx][c], a);
+                        acc[((o * K + r) * K + sx) * 3 + c] = a;
+                    }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const float sum = wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < NW)
+        slab[(int64_t)blockIdx.x * NW + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <int NW>
+__global__ void tiny33_wgrad_reduce_kernel(const float* __restrict__ slab, int nblocks, float* __restrict__ dw) {
+    double sum = 0.0;                                             // one wave per filter entry
+    for (int b = threadIdx.x; b < nblocks; b += 64) sum += (double)slab[(int64_t)b * NW + blockIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (threadIdx.x == 0) dw[blockIdx.x] = (float)sum;
+}
+
+static bool tiny33_ok(const ConvGeom& g) {
+    return g.Cin == 3 && g.Cout == 3 && g.W % 8 == 0 && g.stride == 1 && !g.up && (g.k == 1 || g.k == 3) &&
+           g.pad == g.k / 2 && g.Ho == g.H && g.Wo == g.W;
+}
+static int tiny33_blocks(const ConvGeom& g) {
+    int64_t n = (g.M / 8 + 255) / 256;
+    if (n > 1024) n = 1024;
+    return (int)(n < 1 ? 1 : n);
+}
+
 // ------------------------------------------------------------------------------------ host
 static size_t thin_in_lds(const ConvGeom& g, int dtype) {
     const int nchunk = (g.Cout + kCoChunk - 1) / kCoChunk;
@@ -449,6 +621,19 @@ int conv_fwd_thin(const ConvGeom& g, int dtype, const void* x, const void* w, co
     if (dtype == VAMD_BF16) {
         if (g.Cin <= kSm && thin_in_mfma_ok(g)) return thin_in_mfma(g, x, w, bias, temb, res, res2, y, st);
         if (g.Cin > kSm && thin_out_mfma_ok(g)) return thin_out_mfma(g, x, w, bias, temb, res, res2, y, st);
+    }
+    if (tiny33_ok(g)) {
+        VAMD_DISPATCH(dtype, "conv_fwd_thin", {
+            const dim3 grid((unsigned)((g.M / 8 + 255) / 256 > 4096 ? 4096 : (g.M / 8 + 255) / 256));
+            if (g.k == 3)
+                hipLaunchKernelGGL((tiny33_fwd_kernel<T, 3>), grid, dim3(256), 0, st, g, (const T*)x, (const T*)w, bias, temb,
+                                   (const T*)res, (const T*)res2, (T*)y);
+            else
+                hipLaunchKernelGGL((tiny33_fwd_kernel<T, 1>), grid, dim3(256), 0, st, g, (const T*)x, (const T*)w, bias, temb,
+                                   (const T*)res, (const T*)res2, (T*)y);
+        });
+        VAMD_LAUNCH_OK("tiny33_fwd");
+        return 0;
     }
     VAMD_DISPATCH(dtype, "conv_fwd_thin", {
         if (g.Cin <= kSm) {
@@ -540,6 +725,20 @@ int conv_wgrad_thin(const ConvGeom& g, int dtype, const void* dy, const void* x,
         return fail(VAMD_EINVAL, "conv_wgrad_thin: needs %zu workspace bytes", conv_wgrad_thin_workspace(g, dtype));
     if (dtype == VAMD_BF16 && thin_wgrad_mfma_ok(g)) return thin_wgrad_mfma(g, dy, x, dw, workspace, st);
     float* slab = reinterpret_cast<float*>(workspace);
+    if (tiny33_ok(g)) {
+        const int nb = tiny33_blocks(g);
+        VAMD_DISPATCH(dtype, "conv_wgrad_thin", {
+            if (g.k == 3) {
+                hipLaunchKernelGGL((tiny33_wgrad_kernel<T, 3>), dim3(nb), dim3(256), 0, st, g, (const T*)dy, (const T*)x, slab);
+                hipLaunchKernelGGL((tiny33_wgrad_reduce_kernel<81>), dim3(81), dim3(64), 0, st, slab, nb, dw);
+            } else {
+                hipLaunchKernelGGL((tiny33_wgrad_kernel<T, 1>), dim3(nb), dim3(256), 0, st, g, (const T*)dy, (const T*)x, slab);
+                hipLaunchKernelGGL((tiny33_wgrad_reduce_kernel<9>), dim3(9), dim3(64), 0, st, slab, nb, dw);
+            }
+        });
+        VAMD_LAUNCH_OK("tiny33_wgrad");
+        return 0;
+    }
     const bool wide_out = g.Cin <= kSm;
     VAMD_DISPATCH(dtype, "conv_wgrad_thin", {
         if (g.k == 3) {

@@ -390,6 +390,37 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, T* __restrict_
     }
 }
 
+// Every convolution of a model in one launch: block -> item by a search over the items' first blocks.
+template <typename T>
+__global__ void __launch_bounds__(256)
+repack_weights_kernel(const vamd_repack_item* __restrict__ items, int n) {
+    int lo = 0, hi = n - 1;                                  // last item whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const vamd_repack_item it = items[lo];
+    const int O = it.Cout, I = it.Cin, k = it.ksize;
+    const float* __restrict__ w = it.w;
+    T* __restrict__ wf = (T*)it.w_fwd;
+    T* __restrict__ wd = (T*)it.w_dgrad;
+    const int64_t total = (int64_t)O * I * k * k;
+    const int64_t base = ((int64_t)blockIdx.x - it.first_block) * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t idx = base + q * 256 + threadIdx.x;
+        if (idx >= total) break;
+        const int i = (int)(idx % I);
+        int64_t rest = idx / I;
+        const int s = (int)(rest % k); rest /= k;
+        const int r = (int)(rest % k);
+        const int o = (int)(rest / k);
+        const float v = w[(((int64_t)o * I + i) * k + r) * k + s];
+        wf[idx] = from_f<T>(v);
+        if (wd) wd[(((int64_t)i * k + (k - 1 - r)) * k + (k - 1 - s)) * O + o] = from_f<T>(v);
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwk, float* __restrict__ dw, int O,
                                     int I, int k) {
     const int64_t total = (int64_t)O * I * k * k;
@@ -638,6 +669,17 @@ int vamd_repack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, in
                            as_stream(stream), w, (T*)wf, (T*)wd, Cout, Cin, ksize);
     });
     VAMD_LAUNCH_OK("vamd_repack_weight");
+    return 0;
+}
+
+int vamd_repack_weights(const vamd_repack_item* items_dev, int n, long long total_blocks, int dtype, void* stream) {
+    VAMD_REQUIRE(items_dev && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31),
+                 "vamd_repack_weights: bad argument");
+    VAMD_DISPATCH(dtype, "vamd_repack_weights", {
+        hipLaunchKernelGGL(repack_weights_kernel<T>, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream),
+                           items_dev, n);
+    });
+    VAMD_LAUNCH_OK("vamd_repack_weights");
     return 0;
 }
 

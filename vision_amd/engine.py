@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, call, lib
+from ._lib import ConvDesc, RepackItem, call, lib
 from .plan import LayerSpec, UNetPlan
 
 LEAKY_SLOPE = 0.01          # nn.LeakyReLU() default (reference models/ddpm.py:144)
@@ -472,6 +472,7 @@ class Engine:
         self._lows = {spec.prefix: self._layer_low(spec.prefix) for spec in plan.layers}
         self._lows["End"] = self._layer_low("End")
         self.dirty = True
+        self._repack_table = None
         self.drop_generator = None
         self.profile = None               # list -> receives (kind, flops, start, end) per MFMA conv launch
         self.debug_taps = None            # dict -> receives (output, folded skip) per layer (diagnostics)
@@ -524,8 +525,18 @@ class Engine:
         """Re-pack the compute-dtype weight copies if any master weight changed."""
         vers = [p._version for p in self._params]
         if self.dirty or vers != self._versions:
-            for c in self.all_convs():
-                c.repack()
+            if self._repack_table is None:                    # device table of every conv, built once
+                convs = list(self.all_convs())
+                items = (RepackItem * len(convs))()
+                blocks = 0
+                for it, c in zip(items, convs):
+                    it.w, it.w_fwd, it.w_dgrad = c.w.data_ptr(), c.wf.data_ptr(), c.wd.data_ptr()
+                    it.first_block, it.Cout, it.Cin, it.ksize = blocks, c.cout, c.cin, c.k
+                    blocks += (c.cout * c.cin * c.k * c.k + 1023) // 1024
+                raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+                self._repack_table = (raw, len(convs), blocks)
+            raw, n, blocks = self._repack_table
+            call("vamd_repack_weights", _ptr(raw), n, blocks, self.dt, _stream())
             self._versions = vers
             self.dirty = False
 
