@@ -91,10 +91,15 @@ size_t vamd_conv2d_dgrad_workspace(const vamd_conv_desc* d);
 /* dw[Cout][kh][kw][Cin] (fp32) = sum over pixels of dy (x) x.  Overwrites dw.  If `dbias` is not
  * NULL, dbias[Cout] (fp32) = sum over pixels of dy is written too: the bias gradient comes out of
  * the same pass over dy (the MFMA kernel multiplies the staged dy tile by a column of ones).
- * `workspace` must hold vamd_conv2d_wgrad_workspace(d) bytes (partial sums of the thin-channel
- * kernels; 0 otherwise). */
+ * `workspace` (16-byte aligned) must hold vamd_conv2d_wgrad_workspace(d) bytes: the pixel range is
+ * split over workgroups, every split stores its partial product there, and a second kernel adds
+ * them in a fixed order (no atomics: the result is deterministic). */
 int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same with dw in torch's layout [Cout][Cin][kh][kw]: writes the parameter's .grad directly
+ * (autograd of nn.Conv2d, models/ddpm.py:52-64), no vamd_unpack_wgrad pass. */
+int vamd_conv2d_wgrad_oihw(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
+                           void* workspace, size_t workspace_bytes, void* stream);
 size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d);
 
 /* 1 if the MFMA implicit-GEMM kernels serve this descriptor for pass 0 (forward), 1 (input

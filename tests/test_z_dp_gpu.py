@@ -1,4 +1,4 @@
-"""Two data-parallel ranks on ONE MI355X (both on cuda:0, gloo carrying the device tensors): the
+"""Two data-parallel ranks on ONE MI355X (both on cuda:0; gloo, device tensors staged through host memory): the
 engine's backward issues the bucketed gradient all-reduce through GradReducer, FusedAdamW waits
 for it, buffers are broadcast from rank 0.  Checked against a single-process run of the same two
 per-rank batches: reduced gradients = mean of the per-rank gradients (fp32 compute, 1e-5), and
@@ -6,6 +6,7 @@ both ranks hold identical parameters after two optimizer steps.  RCCL itself is 
 `bench.py --gpus N` on a multi-GPU node; this test covers everything around the collective."""
 import os
 import socket
+import time
 
 import pytest
 import torch
@@ -73,7 +74,13 @@ def _worker(rank, world, port, out_dir):
 def test_two_ranks_match_single_process(tmp_path):
     import vision_amd
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ctx = mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+    deadline = time.time() + 90
+    while not ctx.join(timeout=5):                     # never leave the suite hanging on a stuck rank
+        if time.time() > deadline:
+            for proc in ctx.processes:
+                proc.kill()
+            pytest.fail("data-parallel ranks did not finish within 90 s")
     r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
     r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
     # identical reduced gradients and parameters on both ranks

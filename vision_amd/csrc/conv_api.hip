@@ -167,30 +167,58 @@ int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, 
     return conv_dgrad_direct(g, d->dtype, dy, w_t, add, dx, as_stream(stream));
 }
 
+// workspace layout of the thin / direct kernels when the caller wants torch's layout: their own
+// scratch first, then a [Cout][k][k][Cin] fp32 staging copy of the gradient
+static size_t staging_offset(const ConvGeom& g, int dtype, int a) {
+    const size_t own = a == kThin ? conv_wgrad_thin_workspace(g, dtype) : 0;
+    return (own + 255) / 256 * 256;
+}
+
 size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_wgrad_workspace")) return 0;
     const int a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), "", g);
-    return a == kThin ? conv_wgrad_thin_workspace(g, d->dtype) : 0;
+    if (a == kMfma) return conv_wgrad_mfma_workspace(g, d->dtype);
+    return staging_offset(g, d->dtype, a) + (size_t)g.Cout * g.k * g.k * g.Cin * sizeof(float);
 }
 
-int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+static int conv2d_wgrad_impl(const char* who, const vamd_conv_desc* d, const void* dy, const void* x, float* dw,
+                             float* dbias, int oihw, void* workspace, size_t workspace_bytes, void* stream) {
     ConvGeom g;
-    int rc = conv_geom(d, &g, "vamd_conv2d_wgrad");
+    int rc = conv_geom(d, &g, who);
     if (rc) return rc;
-    VAMD_REQUIRE(dy && x && dw, "vamd_conv2d_wgrad: null tensor");
-    VAMD_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dw % 16 == 0,
-                 "vamd_conv2d_wgrad: tensors must be 16-byte aligned");
-    const int a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), "vamd_conv2d_wgrad", g);
+    VAMD_REQUIRE(dy && x && dw, "%s: null tensor", who);
+    VAMD_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dw % 16 == 0 && (uintptr_t)workspace % 16 == 0,
+                 "%s: tensors must be 16-byte aligned", who);
+    const int a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), who, g);
     if (a < 0) return a;
-    if (a == kMfma) return conv_wgrad_mfma(g, d->dtype, dy, x, dw, dbias, as_stream(stream));
+    if (a == kMfma)
+        return conv_wgrad_mfma(g, d->dtype, dy, x, dw, dbias, oihw, workspace, workspace_bytes, as_stream(stream));
     if (dbias) {                     // the other kernels do not produce it: one extra pass over dy
         rc = column_sums(d->dtype, dy, g.M, g.Cout, dbias, as_stream(stream));
         if (rc) return rc;
     }
-    if (a == kThin) return conv_wgrad_thin(g, d->dtype, dy, x, dw, workspace, workspace_bytes, as_stream(stream));
-    return conv_wgrad_direct(g, d->dtype, dy, x, dw, as_stream(stream));
+    float* out = dw;
+    const size_t off = staging_offset(g, d->dtype, a);
+    if (oihw && g.k > 1) {
+        VAMD_REQUIRE(workspace && workspace_bytes >= off + (size_t)g.Cout * g.k * g.k * g.Cin * sizeof(float),
+                     "%s: workspace too small", who);
+        out = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + off);
+    }
+    if (a == kThin) rc = conv_wgrad_thin(g, d->dtype, dy, x, out, workspace, workspace_bytes < off ? workspace_bytes : off, as_stream(stream));
+    else rc = conv_wgrad_direct(g, d->dtype, dy, x, out, as_stream(stream));
+    if (rc || out == dw) return rc;
+    return vamd_unpack_wgrad(out, dw, g.Cout, g.Cin, g.k, stream);
+}
+
+int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_wgrad_impl("vamd_conv2d_wgrad", d, dy, x, dw, dbias, 0, workspace, workspace_bytes, stream);
+}
+
+int vamd_conv2d_wgrad_oihw(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_wgrad_impl("vamd_conv2d_wgrad_oihw", d, dy, x, dw, dbias, 1, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -991,17 +991,20 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 
     // D layout: column (second operand index) = lane & 15, row (first operand index) = 4*(lane>>4)+r
     const int fr = lane & 15, fq = lane >> 4;
+    // Split-K without atomics: every pixel slice stores its own partial product [slice][N][ldc]
+    // (and partial bias sums [slice][N]); wgrad_reduce_kernel adds the slices in a fixed order.
     if (do_bias && fr == 0) {
+        float* pb = dbias + (int64_t)slice * N;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int nrow = n0 + wm * 64 + i * 16 + fq * 4 + r;
-                if (nrow < N) atomicAdd(dbias + nrow, accb[i][r]);
+                if (nrow < N) pb[nrow] = accb[i][r];
             }
     }
     if (out_mode == 0) {
-        // dW[n][f] fp32, atomically accumulated across split-K slices
+        float* part = dw + (int64_t)slice * N * ldc;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1010,8 +1013,7 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int nrow = n0 + wm * 64 + i * 16 + fq * 4 + r;
-                    if (nrow < N && fcol < gp.Ktot)
-                        atomicAdd(dw + (int64_t)blockIdx.z * strideC + (int64_t)nrow * ldc + fcol, acc[i][j][r]);
+                    if (nrow < N && fcol < gp.Ktot) part[(int64_t)nrow * ldc + fcol] = acc[i][j][r];
                 }
             }
     } else {
@@ -1264,6 +1266,102 @@ bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype) {
     return tn_shape_ok(g.Cin, g.Cout, g.M, dtype);
 }
 
+// Pixel slices of the weight gradient: one workgroup per CU-slot when the filter has few tiles (each
+// slice then runs longer and the partial buffer stays small), two rounds' worth when it has many;
+// at least 8 K-steps per slice, every slice non-empty.
+static int tn_slice_cap(int tiles) {
+    static const int v = [] { const char* e = getenv("VAMD_TN_BLOCKS"); return e ? atoi(e) : 0; }();
+    return v > 0 ? v : (tiles >= 64 ? 1024 : 512);
+}
+static void tn_split(int tiles, int total_steps, int* slices_out, int* steps_per_out) {
+    int slices = tn_slice_cap(tiles) / tiles;
+    const int max_slices = (total_steps + 7) / 8;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    const int steps_per = (total_steps + slices - 1) / slices;
+    *slices_out = (total_steps + steps_per - 1) / steps_per;
+    *steps_per_out = steps_per;
+}
+// tile shape the weight-gradient launcher picks: narrow outputs (Cout <= 64) take a 64 x 192 tile,
+// which wastes no MFMA rows and divides 9 * Cin
+static bool tn_narrow(int N, int Ktot) { return N <= 64 && Ktot >= 192; }
+static int tn_wgrad_slices(const ConvGeom& g, int dtype) {
+    const int Ktot = g.k * g.k * g.Cin, KP = dtype == VAMD_BF16 ? 64 : 32;
+    const bool narrow = tn_narrow(g.Cout, Ktot);
+    const int AN = narrow ? 64 : 128, BF = narrow ? 192 : 128;
+    int slices, steps_per;
+    tn_split(((g.Cout + AN - 1) / AN) * ((Ktot + BF - 1) / BF), (int)((g.M + KP - 1) / KP), &slices, &steps_per);
+    return slices;
+}
+
+// Sums the slices' partial products and writes the gradient either as [Cout][k][k][Cin] or in
+// torch's [Cout][Cin][k][k].  A block covers 256/SL groups of 4 consecutive filter columns with SL
+// slice lanes each (SL = 32 when there are many slices and few outputs); the blocks after those
+// sum the bias partials.  The order of the additions depends only on the shape.
+template <int SL>
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ parts, const float* __restrict__ bias_parts, int slices, int N, int Ktot,
+                    int Cin, int k, int oihw, float* __restrict__ dw, float* __restrict__ dbias) {
+    constexpr int OG = 256 / SL;
+    __shared__ float4 red[SL][OG];
+    const int tx = threadIdx.x % OG, ty = threadIdx.x / OG;
+    const int main_blocks = (int)(((int64_t)N * Ktot / 4 + OG - 1) / OG);
+    if ((int)blockIdx.x >= main_blocks) {                 // bias: 8 channels x 32 slice lanes per block
+        float* redf = reinterpret_cast<float*>(red);
+        const int n = ((int)blockIdx.x - main_blocks) * 8 + (threadIdx.x & 7), lane_s = threadIdx.x >> 3;
+        float sum = 0.f;
+        if (n < N)
+            for (int sl = lane_s; sl < slices; sl += 32) sum += bias_parts[(int64_t)sl * N + n];
+        redf[threadIdx.x] = sum;
+        __syncthreads();
+        if (lane_s == 0 && n < N) {
+            float tot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) tot += redf[i * 8 + (threadIdx.x & 7)];
+            dbias[n] = tot;
+        }
+        return;
+    }
+    const int64_t total4 = (int64_t)N * Ktot / 4;
+    const int64_t q = (int64_t)blockIdx.x * OG + tx;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (q < total4) {
+        const float4* src = reinterpret_cast<const float4*>(parts) + q;
+        int sl = ty;
+        for (; sl + 3 * SL < slices; sl += 4 * SL) {            // four loads in flight
+            const float4 v0 = src[(int64_t)sl * total4], v1 = src[(int64_t)(sl + SL) * total4];
+            const float4 v2 = src[(int64_t)(sl + 2 * SL) * total4], v3 = src[(int64_t)(sl + 3 * SL) * total4];
+            s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+            s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+            s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+            s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+        }
+        for (; sl < slices; sl += SL) {
+            const float4 v = src[(int64_t)sl * total4];
+            s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        }
+    }
+    red[ty][tx] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                              (s0.w + s1.w) + (s2.w + s3.w));
+    __syncthreads();
+    if (ty != 0 || q >= total4) return;
+    float4 r4 = red[0][tx];
+#pragma unroll
+    for (int i = 1; i < SL; ++i) {
+        const float4 v = red[i][tx];
+        r4.x += v.x; r4.y += v.y; r4.z += v.z; r4.w += v.w;
+    }
+    if (!oihw || k == 1) {
+        reinterpret_cast<float4*>(dw)[q] = r4;
+        return;
+    }
+    const int64_t e = q * 4;                            // (n, tap, c .. c+3): Cin % 4 == 0 keeps one tap
+    const int n = (int)(e / Ktot), f = (int)(e - (int64_t)n * Ktot);
+    const int tap = f / Cin, c = f - tap * Cin;
+    float* o = dw + ((int64_t)n * Cin + c) * (k * k) + tap;
+    o[0] = r4.x; o[k * k] = r4.y; o[2 * k * k] = r4.z; o[3 * k * k] = r4.w;
+}
+
 template <typename T, int AN, int BF>
 static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
                            int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, float* dbias,
@@ -1278,18 +1376,8 @@ static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int
     }
     const int n_tiles = (N + AN - 1) / AN, f_tiles = (gp.Ktot + BF - 1) / BF;
     const int total_steps = (gp.M + KP - 1) / KP;
-    int slices = 1;
-    if (out_mode == 0) {
-        // enough workgroups to fill 256 CUs x 2, but at least 8 K-steps per slice
-        // at most 1024 workgroups (two per CU at once): a few more would cost a whole extra round
-        const int tiles = n_tiles * f_tiles * batch;
-        slices = 1024 / tiles;
-        const int max_slices = (total_steps + 7) / 8;
-        if (slices > max_slices) slices = max_slices;
-        if (slices < 1) slices = 1;
-    }
-    const int steps_per = (total_steps + slices - 1) / slices;
-    slices = (total_steps + steps_per - 1) / steps_per;
+    int slices = 1, steps_per = total_steps;
+    if (out_mode == 0) tn_split(n_tiles * f_tiles, total_steps, &slices, &steps_per);
     dim3 grid(n_tiles * f_tiles * slices, 1, batch);
     TimedLaunch timed(TIMED_TN, 2.0 * gp.M * N * gp.Ktot * batch, st);
     hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
@@ -1302,21 +1390,40 @@ template <typename T>
 static int launch_tn(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
                      int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, float* dbias,
                      hipStream_t st) {
-    // narrow outputs (Cout <= 64): a 64 x 192 tile wastes no MFMA rows and 192 divides 9*Cin
-    if (out_mode == 0 && N <= 64 && gp.Ktot >= 192)
+    if (out_mode == 0 && tn_narrow(N, gp.Ktot))
         return launch_tn_shape<T, 64, 192>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, st);
     return launch_tn_shape<T, 128, 128>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, st);
 }
 
+size_t conv_wgrad_mfma_workspace(const ConvGeom& g, int dtype) {
+    return (size_t)tn_wgrad_slices(g, dtype) * ((size_t)g.Cout * g.k * g.k * g.Cin + g.Cout) * sizeof(float);
+}
+
 int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
-                    hipStream_t st) {
+                    int oihw, void* workspace, size_t workspace_bytes, hipStream_t st) {
     Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)g.Cout * gp.Ktot * sizeof(float), st);
-    if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)g.Cout * sizeof(float), st);
-    if (e != hipSuccess) return fail((int)e, "conv_wgrad_mfma: memset failed: %s", hipGetErrorString(e));
+    if (!workspace || workspace_bytes < conv_wgrad_mfma_workspace(g, dtype))
+        return fail(VAMD_EINVAL, "conv_wgrad_mfma: needs %zu workspace bytes", conv_wgrad_mfma_workspace(g, dtype));
+    if (gp.Ktot % 4) return fail(VAMD_EUNSUPPORTED, "conv_wgrad_mfma: k*k*Cin must be a multiple of 4");
+    const int slices = tn_wgrad_slices(g, dtype);
+    float* parts = reinterpret_cast<float*>(workspace);
+    float* bias_parts = dbias ? parts + (size_t)slices * g.Cout * gp.Ktot : nullptr;
+    int rc;
     if (dtype == VAMD_BF16)
-        return launch_tn<bf16_t>(gp, (const bf16_t*)dy, (const bf16_t*)x, g.Cout, g.Cout, gp.Ktot, dw, 1, 0, 0, 0, 0, nullptr, 1.f, dbias, st);
-    return launch_tn<float>(gp, (const float*)dy, (const float*)x, g.Cout, g.Cout, gp.Ktot, dw, 1, 0, 0, 0, 0, nullptr, 1.f, dbias, st);
+        rc = launch_tn<bf16_t>(gp, (const bf16_t*)dy, (const bf16_t*)x, g.Cout, g.Cout, gp.Ktot, parts, 1, 0, 0, 0, 0, nullptr, 1.f, bias_parts, st);
+    else
+        rc = launch_tn<float>(gp, (const float*)dy, (const float*)x, g.Cout, g.Cout, gp.Ktot, parts, 1, 0, 0, 0, 0, nullptr, 1.f, bias_parts, st);
+    if (rc) return rc;
+    const int64_t total4 = (int64_t)g.Cout * gp.Ktot / 4;
+    const unsigned bias_blocks = dbias ? (unsigned)((g.Cout + 7) / 8) : 0u;
+    if (slices >= 32)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((unsigned)((total4 + 7) / 8) + bias_blocks), dim3(256), 0, st, parts,
+                           bias_parts, slices, g.Cout, gp.Ktot, g.Cin, g.k, oihw, dw, dbias);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total4 + 63) / 64) + bias_blocks), dim3(256), 0, st, parts,
+                           bias_parts, slices, g.Cout, gp.Ktot, g.Cin, g.k, oihw, dw, dbias);
+    VAMD_LAUNCH_OK("wgrad_reduce");
+    return 0;
 }
 
 // Batched products for the attention core on the same kernels.  Rows may be padded: lda/ldb/ldc

@@ -55,8 +55,9 @@ size_t conv_dgrad_mfma_workspace(const ConvGeom& g, int dtype);
 int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt, const void* add,
                     void* dx, void* workspace, size_t workspace_bytes, hipStream_t st);
 bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype);
+size_t conv_wgrad_mfma_workspace(const ConvGeom& g, int dtype);
 int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
-                    hipStream_t st);
+                    int oihw, void* workspace, size_t workspace_bytes, hipStream_t st);
 
 // batched products for the attention core on the MFMA kernels (rows may be padded: ld = row stride)
 bool bmm_nt_mfma_supported(int M, int N, int K, int lda, int ldb, int ldc, int dtype, int out_f32);

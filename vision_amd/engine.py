@@ -129,16 +129,9 @@ class _Conv:
         d = self.desc(B, H, W)
         nbytes = lib.vamd_conv2d_wgrad_workspace(C.byref(d))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-        if self.k == 1:
-            call("vamd_conv2d_wgrad", C.byref(d), _ptr(dy), _ptr(x), _ptr(self.gw), gb, _ptr(ws), nbytes, _stream())
-            if ev is not None:
-                ev.record()
-        else:
-            tmp = torch.empty(self.gw.numel(), dtype=torch.float32, device=x.device)
-            call("vamd_conv2d_wgrad", C.byref(d), _ptr(dy), _ptr(x), _ptr(tmp), gb, _ptr(ws), nbytes, _stream())
-            if ev is not None:
-                ev.record()
-            call("vamd_unpack_wgrad", _ptr(tmp), _ptr(self.gw), self.cout, self.cin, self.k, _stream())
+        call("vamd_conv2d_wgrad_oihw", C.byref(d), _ptr(dy), _ptr(x), _ptr(self.gw), gb, _ptr(ws), nbytes, _stream())
+        if ev is not None:
+            ev.record()
 
 
 class _Linear:

@@ -24,6 +24,21 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(t: torch.Tensor, group) -> bool:
+    """Device tensors go through the collective directly only with nccl (RCCL).  Any other backend
+    (gloo: tests, rehearsals of several ranks on one GPU) gets them staged through host memory."""
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def broadcast(t: torch.Tensor, src: int, group=None):
+    if not _staged(t, group):
+        dist.broadcast(t, src=src, group=group)
+        return
+    host = t.cpu()
+    dist.broadcast(host, src=src, group=group)
+    t.copy_(host)
+
+
 def world_info(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
@@ -34,8 +49,8 @@ class GradReducer:
     """Bucketed, overlapped mean all-reduce of a flat gradient arena.
 
     `boundaries` are arena offsets (ascending) at which a layer's parameters start; gradients
-    become final from the last boundary backwards.  Device-agnostic: works on CPU tensors with
-    the gloo backend (used by the multi-process tests) and on GPU tensors with nccl/RCCL."""
+    become final from the last boundary backwards.  GPU tensors go to nccl/RCCL directly; with
+    any other backend (gloo) they are staged through host memory, CPU tensors are used as they are."""
 
     def __init__(self, flat_grads: torch.Tensor, boundaries: List[int], group=None, bucket_bytes=25 << 20):
         self.flat, self.group = flat_grads, group
@@ -74,23 +89,34 @@ class GradReducer:
             return
         view = self.flat[lo:hi]
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+        if _staged(view, self.group):
+            # fallback transport: the slice is copied to the host (this waits for the kernels that
+            # produced it), reduced there, and copied back in wait()
+            host = view.cpu()
+            work = None if self._serial else dist.all_reduce(host, op=op, group=self.group, async_op=True)
+            if self._serial:
+                dist.all_reduce(host, op=op, group=self.group)
+            self._pending.append((work, view, host))
+            return
         # async_op: the collective runs on the backend's own stream after everything already
         # queued on the current stream (the kernels that produced this slice), while later
         # backward kernels keep the compute stream busy
         if self._serial:
             dist.all_reduce(view, op=op, group=self.group)
-            self._pending.append((None, view))
+            self._pending.append((None, view, None))
             return
         work = dist.all_reduce(view, op=op, group=self.group, async_op=True)
-        self._pending.append((work, view))
+        self._pending.append((work, view, None))
 
     def wait(self):
         """Block the current stream (not the host, on GPU) until every issued bucket has landed."""
         if self._next < len(self.buckets):
             self.finish()
-        for work, view in self._pending:
+        for work, view, host in self._pending:
             if work is not None:
                 work.wait()
+            if host is not None:
+                view.copy_(host)
             if not self._use_avg:
                 view.mul_(1.0 / self.world)
         self._pending = []
@@ -108,7 +134,7 @@ class DataParallel:
         model.grad_reducer = self.reducer
         eng.reducer = self.reducer
         if self.world > 1:
-            dist.broadcast(eng.flat_p, src=self._src(), group=group)       # identical start on every rank
+            broadcast(eng.flat_p, self._src(), group)       # identical start on every rank
             eng.dirty = True
             self.broadcast_buffers()
 
@@ -121,14 +147,18 @@ class DataParallel:
         if self.world == 1:
             return
         eng = self.engine
-        dist.broadcast(eng.flat_b, src=self._src(), group=self.group)
-        dist.broadcast(eng.flat_nbt, src=self._src(), group=self.group)
+        broadcast(eng.flat_b, self._src(), self.group)
+        broadcast(eng.flat_nbt, self._src(), self.group)
 
     def all_reduce_scalar_mean(self, value: torch.Tensor) -> torch.Tensor:
         """`self.log(..., sync_dist=True)` of the reference (models/ddpm.py:314,327,337)."""
         if self.world == 1:
             return value
         v = value.detach().clone()
+        if _staged(v, self.group):
+            host = v.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            return host.to(v.device) / self.world
         dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
         return v / self.world
 
@@ -157,5 +187,5 @@ def generate_sharded(model, initial_noise: torch.Tensor, diffusion_steps: int, g
     for r in range(world):                      # rows per rank may differ by one: one broadcast each
         if parts[r].numel():
             src = dist.get_global_rank(group, r) if group is not None else r
-            dist.broadcast(parts[r], src=src, group=group)
+            broadcast(parts[r], src, group)
     return torch.cat(parts, 0)
