@@ -112,8 +112,8 @@ int vamd_repack_weight(const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout
                        int ksize, int dtype, void* stream);
 /* The same for every convolution of a model in ONE launch (the weight refresh after an optimiser
  * step, models/ddpm.py:339-352 -> next forward).  `items` is an array of n entries in DEVICE
- * memory; entry i covers blocks [first_block, first_block + ceil(Cout*Cin*k*k / 1024)), entries in
- * ascending first_block order starting at 0; total_blocks = the sum of the counts. */
+ * memory; entry i covers blocks [first_block, first_block + ceil(Cout/32) * ceil(Cin/32)), entries
+ * in ascending first_block order starting at 0; total_blocks = the sum of the counts. */
 typedef struct vamd_repack_item {
     const float* w;        /* fp32 [Cout][Cin][k][k] */
     void* w_fwd;           /* [Cout][k][k][Cin] in dtype */

@@ -468,3 +468,30 @@ def test_adamw_matches_torch():
         opt.step()
         call("vamd_adamw", P(p), P((2 * g).to(DEV)), P(m), P(v), n, 1e-2, None, 0.9, 0.999, 1e-8, 0.1, step, 0.5, S())
     assert relerr(p, ref.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+def test_repack_weights_batched_matches_single(dts):
+    """One launch over a table of convolutions == vamd_repack_weight per convolution."""
+    from vision_amd._lib import RepackItem
+    dt, tdt = (_lib.F32, torch.float32) if dts == "f32" else (_lib.BF16, torch.bfloat16)
+    shapes = [(64, 3, 3), (3, 64, 3), (3, 3, 1), (40, 72, 3), (128, 64, 1), (33, 31, 3), (96, 96, 3)]
+    gen = torch.Generator().manual_seed(5)
+    items = (RepackItem * len(shapes))()
+    keep, blocks = [], 0
+    for it, (O, I, k) in zip(items, shapes):
+        w = torch.randn((O, I, k, k), generator=gen).to(DEV)
+        wf = torch.full((O, k, k, I), 7.0, dtype=tdt, device=DEV)
+        wd = torch.full((I, k, k, O), 7.0, dtype=tdt, device=DEV)
+        wf1, wd1 = torch.empty_like(wf), torch.empty_like(wd)
+        call("vamd_repack_weight", P(w), P(wf1), P(wd1), O, I, k, dt, S())
+        it.w, it.w_fwd, it.w_dgrad = w.data_ptr(), wf.data_ptr(), wd.data_ptr()
+        it.first_block, it.Cout, it.Cin, it.ksize = blocks, O, I, k
+        blocks += ((O + 31) // 32) * ((I + 31) // 32)
+        keep.append((w, wf, wd, wf1, wd1))
+    table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(DEV)
+    call("vamd_repack_weights", P(table), len(shapes), blocks, dt, S())
+    torch.cuda.synchronize()
+    for w, wf, wd, wf1, wd1 in keep:
+        assert torch.equal(wf, wf1) and torch.equal(wd, wd1)
+        assert torch.equal(wf.float(), w.permute(0, 2, 3, 1).to(tdt).float())

@@ -390,34 +390,44 @@ __global__ void repack_weight_kernel(const float* __restrict__ w, T* __restrict_
     }
 }
 
-// Every convolution of a model in one launch: block -> item by a search over the items' first blocks.
+// Every convolution of a model in one launch: block -> item by a search over the items' first
+// blocks, then one 32 (Cout) x 32 (Cin) x k*k tile through LDS, so that the fp32 source is read in
+// contiguous runs and both packed copies are written in 64-byte runs.
 template <typename T>
 __global__ void __launch_bounds__(256)
 repack_weights_kernel(const vamd_repack_item* __restrict__ items, int n) {
+    constexpr int TO = 32, TI = 32;
+    __shared__ float tile[TO][TI * 9 + 1];
     int lo = 0, hi = n - 1;                                  // last item whose first_block <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (items[mid].first_block <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const vamd_repack_item it = items[lo];
-    const int O = it.Cout, I = it.Cin, k = it.ksize;
+    const int O = it.Cout, I = it.Cin, k = it.ksize, kk = k * k;
     const float* __restrict__ w = it.w;
     T* __restrict__ wf = (T*)it.w_fwd;
     T* __restrict__ wd = (T*)it.w_dgrad;
-    const int64_t total = (int64_t)O * I * k * k;
-    const int64_t base = ((int64_t)blockIdx.x - it.first_block) * 1024;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int64_t idx = base + q * 256 + threadIdx.x;
-        if (idx >= total) break;
-        const int i = (int)(idx % I);
-        int64_t rest = idx / I;
-        const int s = (int)(rest % k); rest /= k;
-        const int r = (int)(rest % k);
-        const int o = (int)(rest / k);
-        const float v = w[(((int64_t)o * I + i) * k + r) * k + s];
-        wf[idx] = from_f<T>(v);
-        if (wd) wd[(((int64_t)i * k + (k - 1 - r)) * k + (k - 1 - s)) * O + o] = from_f<T>(v);
+    const int local = (int)((long long)blockIdx.x - it.first_block);
+    const int i_tiles = (I + TI - 1) / TI;
+    const int o0 = (local / i_tiles) * TO, i0 = (local % i_tiles) * TI;
+    const int run = TI * kk;                                 // source floats per output channel in this tile
+    for (int idx = threadIdx.x; idx < TO * run; idx += 256) {
+        const int ol = idx / run, rem = idx - ol * run;
+        const int o = o0 + ol, i = i0 + rem / kk;
+        tile[ol][rem] = (o < O && i < I) ? w[((int64_t)o * I + i0) * kk + rem] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TO * run; idx += 256) {          // wf[o][tap][i]
+        const int il = idx % TI, tap = (idx / TI) % kk, ol = idx / run;
+        const int o = o0 + ol, i = i0 + il;
+        if (o < O && i < I) wf[((int64_t)o * kk + tap) * I + i] = from_f<T>(tile[ol][il * kk + tap]);
+    }
+    if (!wd) return;
+    for (int idx = threadIdx.x; idx < TO * run; idx += 256) {          // wd[i][flipped tap][o]
+        const int ol = idx % TO, tap = (idx / TO) % kk, il = idx / (TO * kk);
+        const int o = o0 + ol, i = i0 + il;
+        if (o < O && i < I) wd[((int64_t)i * kk + (kk - 1 - tap)) * O + o] = from_f<T>(tile[ol][il * kk + tap]);
     }
 }
 

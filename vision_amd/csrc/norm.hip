@@ -8,7 +8,7 @@ namespace vamd {
 
 constexpr int kStatsBlock = 256;
 constexpr int kStatsRowsPerChunk = 256;
-constexpr int kStatsMaxChunks = 512;
+constexpr int kStatsMaxChunks = 1024;
 
 // chunks per group: at least kStatsRowsPerChunk rows each, and about 2048 workgroups over all groups
 static inline int stats_chunks(int64_t R, int G) {
@@ -82,9 +82,8 @@ chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ pa
         }
         const T* dy = (const T*)a.dy;
         const T* mk = (const T*)a.mask;
-        for (int64_t r = r0 + rl; r < r1; r += tr) {
+        auto load = [&](int64_t r, T (&xv)[VEC], T (&dv)[VEC], T (&mv)[VEC]) {
             const int64_t off = ((int64_t)g * R + r) * C + c0;
-            alignas(16) T xv[VEC]; alignas(16) T dv[VEC]; alignas(16) T mv[VEC];
             if (VEC > 1) {
                 *reinterpret_cast<Vec16<T>*>(xv) = *reinterpret_cast<const Vec16<T>*>(x + off);
                 if (MODE == 1) {
@@ -98,6 +97,8 @@ chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ pa
                     if (mk) mv[0] = mk[off];
                 }
             }
+        };
+        auto accumulate = [&](const T (&xv)[VEC], const T (&dv)[VEC], const T (&mv)[VEC]) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float xf = to_f(xv[j]);
@@ -114,6 +115,25 @@ chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ pa
                     s2[j] = fmaf(gz, xh, s2[j]);
                 }
             }
+        };
+        int64_t r = r0 + rl;
+        for (; r + 3 * tr < r1; r += 4 * tr) {                 // four rows' loads in flight per lane
+            alignas(16) T x0[VEC], x1[VEC], x2[VEC], x3[VEC];
+            alignas(16) T d0[VEC], d1[VEC], d2[VEC], d3[VEC];
+            alignas(16) T m0[VEC], m1[VEC], m2[VEC], m3[VEC];
+            load(r, x0, d0, m0);
+            load(r + tr, x1, d1, m1);
+            load(r + 2 * tr, x2, d2, m2);
+            load(r + 3 * tr, x3, d3, m3);
+            accumulate(x0, d0, m0);
+            accumulate(x1, d1, m1);
+            accumulate(x2, d2, m2);
+            accumulate(x3, d3, m3);
+        }
+        for (; r < r1; r += tr) {
+            alignas(16) T xv[VEC]; alignas(16) T dv[VEC]; alignas(16) T mv[VEC];
+            load(r, xv, dv, mv);
+            accumulate(xv, dv, mv);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -283,18 +303,26 @@ fold_partials_kernel(const float* __restrict__ in, int nparts, int width, int no
     out[(int64_t)q * width + w] = (a0 + a1) + (a2 + a3);
 }
 
-template <typename T, int VEC>
+// HOIST: one group and a grid stride that is a multiple of C: a lane's channels never change
+template <typename T, int VEC, bool HOIST>
 __global__ void scale_shift_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                        const float* __restrict__ shift, const T* __restrict__ mask,
                                        float slope, T* __restrict__ y, int64_t RC, int C,
                                        int64_t nvec) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    float sc[VEC], sh[VEC];
+    auto coef = [&](int64_t gc) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            sc[j] = scale[gc + j];
+            sh[j] = shift[gc + j];
+        }
+    };
+    if (HOIST) coef((i0 * VEC) % C);
+    for (int64_t i = i0; i < nvec; i += stride) {
         const int64_t e = i * VEC;
-        const int64_t g = e / RC;
-        const int c = (int)(e % C);
-        const float* sc = scale + g * C + c;
-        const float* sh = shift + g * C + c;
+        if (!HOIST) coef((e / RC) * C + (e % C));
         alignas(16) T xv[VEC]; alignas(16) T mv[VEC]; alignas(16) T yv[VEC];
         if (VEC > 1) {
             *reinterpret_cast<Vec16<T>*>(xv) = *reinterpret_cast<const Vec16<T>*>(x + e);
@@ -322,15 +350,32 @@ struct NormApplyArgs {
     float slope;
 };
 
-template <typename T, int VEC>
+// HOIST: one group (BatchNorm) and a grid stride that is a multiple of C, so a lane keeps its VEC
+// channels for the whole loop and the seven per-channel coefficients are read once.
+template <typename T, int VEC, bool HOIST>
 __global__ void norm_bwd_apply_kernel(NormApplyArgs a, T* __restrict__ dx, int64_t RC, int C,
                                       int64_t nvec) {
     const T* dy = (const T*)a.dy; const T* x = (const T*)a.x; const T* mask = (const T*)a.mask;
     const T* add = (const T*)a.add; const T* add2 = (const T*)a.add2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    float sc[VEC], sh[VEC], mu[VEC], rs[VEC], cA[VEC], cB[VEC], cC[VEC];
+    auto coef = [&](int64_t gc) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            sc[j] = a.scale[gc + j];
+            sh[j] = a.shift[gc + j];
+            mu[j] = a.mean[gc + j];
+            rs[j] = a.rstd[gc + j];
+            cA[j] = a.cA[gc + j];
+            cB[j] = a.cB[gc + j];
+            cC[j] = a.cC[gc + j];
+        }
+    };
+    if (HOIST) coef((i0 * VEC) % C);
+    for (int64_t i = i0; i < nvec; i += stride) {
         const int64_t e = i * VEC;
-        const int64_t gc = (e / RC) * C + (e % C);
+        if (!HOIST) coef((e / RC) * C + (e % C));
         alignas(16) T xv[VEC]; alignas(16) T dv[VEC]; alignas(16) T mv[VEC]; alignas(16) T av[VEC]; alignas(16) T a2v[VEC]; alignas(16) T ov[VEC];
         if (VEC > 1) {
             *reinterpret_cast<Vec16<T>*>(xv) = *reinterpret_cast<const Vec16<T>*>(x + e);
@@ -347,12 +392,12 @@ __global__ void norm_bwd_apply_kernel(NormApplyArgs a, T* __restrict__ dx, int64
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float xf = to_f(xv[j]);
-            const float z = fmaf(xf, a.scale[gc + j], a.shift[gc + j]);
+            const float z = fmaf(xf, sc[j], sh[j]);
             float gz = to_f(dv[j]);
             if (mask) gz *= to_f(mv[j]);
             if (!(z > 0.f)) gz *= a.slope;
-            const float xh = (xf - a.mean[gc + j]) * a.rstd[gc + j];
-            float r = fmaf(a.cA[gc + j], gz, fmaf(a.cC[gc + j], xh, a.cB[gc + j]));
+            const float xh = (xf - mu[j]) * rs[j];
+            float r = fmaf(cA[j], gz, fmaf(cC[j], xh, cB[j]));
             if (add) r += to_f(av[j]);
             if (add2) r += to_f(a2v[j]);
             ov[j] = from_f<T>(r);
@@ -457,11 +502,16 @@ int vamd_scale_shift_act(const void* x, const float* scale, const float* shift, 
     VAMD_DISPATCH(dtype, "vamd_scale_shift_act", {
         constexpr int VEC = Vec16<T>::N;
         if (C % VEC == 0) {
-            hipLaunchKernelGGL((scale_shift_act_kernel<T, VEC>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
-                               as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope,
-                               (T*)y, R * C, C, n / VEC);
+            if (G == 1 && (256 * VEC) % C == 0)
+                hipLaunchKernelGGL((scale_shift_act_kernel<T, VEC, true>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
+                                   as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope,
+                                   (T*)y, R * C, C, n / VEC);
+            else
+                hipLaunchKernelGGL((scale_shift_act_kernel<T, VEC, false>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
+                                   as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope,
+                                   (T*)y, R * C, C, n / VEC);
         } else {
-            hipLaunchKernelGGL((scale_shift_act_kernel<T, 1>), dim3(grid_for(n, 256)), dim3(256), 0,
+            hipLaunchKernelGGL((scale_shift_act_kernel<T, 1, false>), dim3(grid_for(n, 256)), dim3(256), 0,
                                as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope,
                                (T*)y, R * C, C, n);
         }
@@ -511,10 +561,15 @@ int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const f
     VAMD_DISPATCH(dtype, "vamd_norm_bwd_apply", {
         constexpr int VEC = Vec16<T>::N;
         if (C % VEC == 0) {
-            hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
-                               as_stream(stream), a, (T*)dx, R * C, C, n / VEC);
+            // one group and whole channel rows per block: a lane keeps its channels across the grid stride
+            if (G == 1 && (256 * VEC) % C == 0)
+                hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC, true>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
+                                   as_stream(stream), a, (T*)dx, R * C, C, n / VEC);
+            else
+                hipLaunchKernelGGL((norm_bwd_apply_kernel<T, VEC, false>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
+                                   as_stream(stream), a, (T*)dx, R * C, C, n / VEC);
         } else {
-            hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1>), dim3(grid_for(n, 256)), dim3(256), 0,
+            hipLaunchKernelGGL((norm_bwd_apply_kernel<T, 1, false>), dim3(grid_for(n, 256)), dim3(256), 0,
                                as_stream(stream), a, (T*)dx, R * C, C, n);
         }
     });

@@ -525,7 +525,7 @@ class Engine:
                 for it, c in zip(items, convs):
                     it.w, it.w_fwd, it.w_dgrad = c.w.data_ptr(), c.wf.data_ptr(), c.wd.data_ptr()
                     it.first_block, it.Cout, it.Cin, it.ksize = blocks, c.cout, c.cin, c.k
-                    blocks += (c.cout * c.cin * c.k * c.k + 1023) // 1024
+                    blocks += ((c.cout + 31) // 32) * ((c.cin + 31) // 32)
                 raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
                 self._repack_table = (raw, len(convs), blocks)
             raw, n, blocks = self._repack_table
