@@ -78,6 +78,18 @@ template <typename T> __device__ __forceinline__ const T* pick_ptr(bool ok, cons
     return reinterpret_cast<const T*>(((uint64_t)a & m) | ((uint64_t)b & ~m));
 }
 
+// Direct-to-LDS 16-byte load through a buffer resource: the base pointer lives in scalar registers,
+// a lane supplies a 32-bit byte offset, and an offset at or beyond the resource's size (kNoLoad)
+// makes the hardware write zeros - padding taps and rows past the tensor cost one select, no
+// 64-bit pointer arithmetic.  Tensors are < 2 GiB (checked on the host).
+constexpr uint32_t kNoLoad = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ void load16_lds(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, bool ok, unsigned char* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LPTR(lds), 16, (int)(ok ? byte_off : kNoLoad), 0, 0, 0);
+}
+
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<bf16_t> { static constexpr int PIECE = 8; typedef bf16x8_t Frag; };   // elements per 16 bytes
 template <> struct ElemTraits<float> { static constexpr int PIECE = 4; typedef f32x4_t Frag; };
@@ -415,8 +427,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     int a_base[4], a_h0[4], a_w0[4];
     uint32_t a_mask[4];
     int f, c, tr, ts, tap;
-    const T* xz = x;
-    const T* wz = w;
+    __amdgpu_buffer_rsrc_t rx = make_rsrc(x), rw = make_rsrc(w);
     auto advance = [&]() {                               // branch-free: at most two taps per K-step
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -431,8 +442,8 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     };
     auto setup = [&](int row_tile) {                      // staging state of K-step 0 of a tile
         const int z = row_tile / m_tiles, mt = row_tile - z * m_tiles;
-        xz = x + (int64_t)z * strideA;
-        wz = w + (int64_t)z * strideB;
+        rx = make_rsrc(x + (int64_t)z * strideA);
+        rw = make_rsrc(w + (int64_t)z * strideB);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t m = mt * kBM + srow + 32 * i;
@@ -458,7 +469,6 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         advance();
     };
 
-    const T* zero = reinterpret_cast<const T*>(g_zero_page);
     auto stage_a = [&](int buf) {
         unsigned char* sa = smem + buf * STAGE + wave_s * 1024;
         const bool f_ok = f < gp.Ktot;
@@ -469,8 +479,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             int off;
             if constexpr (UP) off = a_base[i] + (((a_h0[i] + tr) >> 1) * gp.Win + ((a_w0[i] + ts) >> 1)) * gp.ldx + c;
             else off = a_base[i] + tapoff;
-            const T* src = pick_ptr(ok, xz + (uint32_t)off, zero);
-            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sa + i * 4096), 16, 0, 0);
+            load16_lds(rx, (uint32_t)off * (uint32_t)sizeof(T), ok, sa + i * 4096);
         }
     };
     auto stage_b = [&](int buf) {
@@ -479,8 +488,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         const int wf = ((gp.wr0 + gp.wstep * tr) * gp.wk + gp.ws0 + gp.wstep * ts) * gp.Cin + c;   // == f for a plain filter
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i) {
-            const T* src = pick_ptr(f_ok & b_ok[i], wz + (uint32_t)(b_off[i] + wf), zero);
-            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sb + i * 4096), 16, 0, 0);
+            load16_lds(rw, (uint32_t)(b_off[i] + wf) * (uint32_t)sizeof(T), f_ok & b_ok[i], sb + i * 4096);
         }
         f += KSTEP;
         c += KSTEP;
@@ -693,6 +701,354 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         for (int idx = tid; idx < BN * 2; idx += 256) {
             const int col = idx >> 1;
             if (n0 + col < N) ep.stats[((int64_t)part * N + n0 + col) * 2 + (idx & 1)] = red[idx] + red[BN * 2 + idx];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wide persistent variant for large layers: 256 pixel rows x BN channels per tile, 8 waves (each
+// still a 64 x BN/2 sub-tile), ONE workgroup per CU and a ring of three K-step stages.  Against the
+// 128-row kernel a tile moves 25 % fewer bytes from L2 per MFMA, and the loads of a K-step are
+// issued two K-steps before they are read: the wait before a K-step's barrier covers the next
+// stage only, the one after it stays in flight across the barrier.  The K-steps of consecutive
+// tiles form one stream, so the ring never drains between tiles.
+template <typename T, int BN, bool UP, bool STATS>
+__global__ void __launch_bounds__(512, 1)
+conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
+                     Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, int row_tiles,
+                     int64_t strideA, int64_t strideB, int64_t strideC) {
+    constexpr int PIECE = ElemTraits<T>::PIECE;          // elements per 16-byte piece
+    constexpr int KSTEP = kRowBytes / sizeof(T);          // reduction elements per K-step
+    constexpr int BM = 256;
+    constexpr int NPA = BM / 64, NPB = BN / 64;           // 16-byte pieces per thread and K-step: pixels, filter rows
+    constexpr int NLOAD = NPA + NPB;
+    constexpr int A_BYTES = BM * kRowBytes;
+    constexpr int B_BYTES = BN * kRowBytes;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NT = BN / 32;                           // 16-wide channel tiles per wave
+    constexpr int CPL = 4 * NT;                           // consecutive output channels per lane
+    using Frag = typename ElemTraits<T>::Frag;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % n_tiles;                          // this workgroup's column tile, fixed
+    const int rstep = gridDim.x / n_tiles;                 // row tiles advance by this
+    int rt = bid / n_tiles;                                // row tile = (batch z, m tile)
+    const int n0 = nt * BN;
+
+    // ---- staging: this thread copies piece `slot` of rows srow + 64*i
+    const int srow = tid >> 3, slot = tid & 7;
+    const int chunk = slot ^ (srow & 7);                 // logical piece held by this LDS slot
+    // filter rows: LDS row R of the wave half h = R / (BN/2), q = R % (BN/2) = 16*jc + i holds
+    // channel h*(BN/2) + (i>>2)*CPL + 4*jc + (i&3)
+    int b_off[NPB];
+    bool b_ok[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int R = srow + 64 * i;
+        const int h = R / (BN / 2), q = R - h * (BN / 2);
+        const int n = n0 + h * (BN / 2) + ((q & 15) >> 2) * CPL + 4 * (q >> 4) + (q & 3);
+        b_ok[i] = n < N;
+        b_off[i] = (b_ok[i] ? n : 0) * ldw;
+    }
+    int a_base[NPA], a_h0[NPA], a_w0[NPA];
+    uint32_t a_mask[NPA];
+    int f, c, tr, ts, tap;
+    __amdgpu_buffer_rsrc_t rx = make_rsrc(x), rw = make_rsrc(w);
+    auto advance = [&]() {                               // branch-free: at most two taps per K-step
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int adv = c >= gp.Cin ? 1 : 0;
+            c -= adv ? gp.Cin : 0;
+            tap += adv;
+            ts += adv;
+            const int wrap = ts == gp.ks ? 1 : 0;
+            ts = wrap ? 0 : ts;
+            tr += wrap;
+        }
+    };
+    auto setup = [&](int row_tile) {                      // staging state of K-step 0 of a tile
+        const int z = row_tile / m_tiles, mt = row_tile - z * m_tiles;
+        rx = make_rsrc(x + (int64_t)z * strideA);
+        rw = make_rsrc(w + (int64_t)z * strideB);
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const uint32_t m = mt * BM + srow + 64 * i;
+            const bool row_ok = m < (uint32_t)gp.M;
+            const uint32_t b = fdiv(m, gp.div_howo);
+            const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
+            const uint32_t ho = fdiv(rem, gp.div_wo);
+            const int h0 = (int)ho * gp.stride - gp.pad;
+            const int w0 = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad;
+            a_h0[i] = h0;
+            a_w0[i] = w0;
+            a_base[i] = UP ? (int)b * gp.Hin * gp.Win * gp.ldx : (((int)b * gp.Hin + h0) * gp.Win + w0) * gp.ldx;
+            uint32_t mask = 0, bit = 1;
+            for (int r = 0; r < gp.kr; ++r) {
+                const bool rok = row_ok && (unsigned)(h0 + r) < (unsigned)gp.He;
+                for (int q = 0; q < gp.ks; ++q, bit <<= 1)
+                    if (rok && (unsigned)(w0 + q) < (unsigned)gp.We) mask |= bit;
+            }
+            a_mask[i] = mask;
+        }
+        f = chunk * PIECE;
+        c = f; tr = 0; ts = 0; tap = 0;
+        advance();
+    };
+
+    auto stage_a = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE + wave_s * 1024;
+        const bool f_ok = f < gp.Ktot;
+        const int tapoff = (tr * gp.Win + ts) * gp.ldx + c;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const bool ok = f_ok & (bool)((a_mask[i] >> (tap & 31)) & 1u);
+            int off;
+            if constexpr (UP) off = a_base[i] + (((a_h0[i] + tr) >> 1) * gp.Win + ((a_w0[i] + ts) >> 1)) * gp.ldx + c;
+            else off = a_base[i] + tapoff;
+            load16_lds(rx, (uint32_t)off * (uint32_t)sizeof(T), ok, sa + i * 8192);
+        }
+    };
+    auto stage_b = [&](int buf) {
+        unsigned char* sb = smem + buf * STAGE + A_BYTES + wave_s * 1024;
+        const bool f_ok = f < gp.Ktot;
+        const int wf = ((gp.wr0 + gp.wstep * tr) * gp.wk + gp.ws0 + gp.wstep * ts) * gp.Cin + c;   // == f for a plain filter
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            load16_lds(rw, (uint32_t)(b_off[i] + wf) * (uint32_t)sizeof(T), f_ok & b_ok[i], sb + i * 8192);
+        }
+        f += KSTEP;
+        c += KSTEP;
+        advance();
+    };
+
+    f32x4_t acc[NT][4];                                   // [channel tile][pixel tile]
+
+    const int frow = lane & 15, fgrp = lane >> 4, fsw = lane & 7;
+    auto read_frags = [&](int buf, int ks, Frag (&a)[4], Frag (&b)[NT]) {
+        const unsigned char* sa = smem + buf * STAGE + (wm * 64 + frow) * kRowBytes;
+        const unsigned char* sb = smem + buf * STAGE + A_BYTES + (wn * (BN / 2) + frow) * kRowBytes;
+        const int po = (((ks * 4 + fgrp) ^ fsw) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const Frag*>(sa + i * 16 * kRowBytes + po);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const Frag*>(sb + j * 16 * kRowBytes + po);
+    };
+    auto mma = [&](const Frag (&a)[4], const Frag (&b)[NT]) {   // D rows = channels, columns = pixels
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][e], a[i][e], acc[j][i], 0, 0, 0);
+        }
+    };
+    // ---- outputs: lane (p = lane & 15, grp = lane >> 4) holds, per pixel tile, channels nb .. nb+CPL-1
+    const int nb = n0 + wn * (BN / 2) + fgrp * CPL;
+    float s1[STATS ? CPL : 1], s2[STATS ? CPL : 1];
+#pragma unroll
+    for (int e = 0; e < (STATS ? CPL : 1); ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    // accumulators start from the bias (alpha is 1 whenever a bias is given)
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (ep.bias) {
+                const int n = nb + 4 * j;
+                if (n + 4 <= N) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(ep.bias + n);
+                    bv = f32x4_t{t4.x, t4.y, t4.z, t4.w};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[r] = n + r < N ? ep.bias[n + r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = bv;
+        }
+    };
+    auto write_tile = [&](int row_tile) {
+        const int z = row_tile / m_tiles, mt = row_tile - z * m_tiles;
+        const T* res = reinterpret_cast<const T*>(ep.res);
+        const T* res2 = reinterpret_cast<const T*>(ep.res2);
+        constexpr int CH = 16 / (int)sizeof(T);           // channels per 16-byte piece of T: 8 (bf16) or 4
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t m = mt * BM + wm * 64 + i * 16 + frow;
+            if (m >= (uint32_t)gp.M) continue;
+            uint32_t bimg = 0;
+            int64_t orow = m;
+            if (gp.ostep || ep.temb) {
+                bimg = fdiv(m, gp.div_howo);
+                if (gp.ostep) {
+                    const uint32_t rem = m - bimg * (uint32_t)(gp.Ho * gp.Wo);
+                    const uint32_t ho = fdiv(rem, gp.div_wo);
+                    const uint32_t wo = rem - ho * gp.Wo;
+                    orow = ((int64_t)bimg * gp.oH + ho * gp.ostep + gp.oph) * gp.oW + wo * gp.ostep + gp.opw;
+                }
+            }
+            const int64_t off = (int64_t)z * strideC + orow * ldc + nb;
+            if (ep.out_f32) {                             // fp32 outputs of a bf16 product (attention scores)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = nb + 4 * j;
+                    // a trailing partial group is written whole: its extra columns are exact zeros
+                    // (their filter rows were never loaded) and ldc leaves room for them
+                    if (n < N && n + 4 <= ldc)
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yout) + off + 4 * j) =
+                            make_float4(acc[j][i][0] * ep.alpha, acc[j][i][1] * ep.alpha, acc[j][i][2] * ep.alpha, acc[j][i][3] * ep.alpha);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int ch = 0; ch < CPL; ch += CH) {         // one 16-byte piece of the output row
+                const int n = nb + ch;
+                if (n >= N || n + CH > ldc) continue;
+                float v[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) v[e] = acc[(ch + e) >> 2][i][e & 3] * ep.alpha;
+                if (ep.temb) {
+                    const float* tp = ep.temb + (int64_t)bimg * N + n;
+                    if (n + CH <= N) {
+#pragma unroll
+                        for (int e = 0; e < CH; e += 4) {
+                            const float4 t4 = *reinterpret_cast<const float4*>(tp + e);
+                            v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) if (n + e < N) v[e] += tp[e];
+                    }
+                }
+                if (res) {
+                    const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res + off + ch);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
+                }
+                if (res2) {
+                    const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res2 + off + ch);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
+                }
+                Vec16<T> ov;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(v[e]);
+                *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + off + ch) = ov;
+                if constexpr (STATS) {                    // statistics of the rounded values a later pass would read
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) {
+                        const float q = to_f(ov.v[e]);
+                        s1[ch + e] += q;
+                        s2[ch + e] = fmaf(q, q, s2[ch + e]);
+                    }
+                }
+            }
+        }
+    };
+
+    const int nk = (gp.Ktot + KSTEP - 1) / KSTEP;
+    // staging runs two K-steps ahead of the MFMAs, through the same (tile, K-step) sequence
+    int s_k = 0;
+    bool s_more = true;
+    auto staged = [&]() {                                  // a stage was issued: move the staging state on
+        if (++s_k == nk) {
+            s_k = 0;
+            rt += rstep;
+            s_more = rt < row_tiles;
+            if (s_more) setup(rt);
+        }
+    };
+    int cur = rt;
+    init_acc();
+    setup(rt);
+    stage_a(0);
+    stage_b(0);
+    staged();
+    if (s_more) {
+        stage_a(1);
+        stage_b(1);
+        staged();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    // Fragments are double-buffered in registers: the reads of one half K-step are in flight while
+    // the MFMAs of the previous half run, so the eight lock-stepped waves never wait on LDS with
+    // the matrix pipe idle.  One barrier per K-step, in its middle: before it a wave has waited for
+    // its own loads of the next stage, after it the first half of that stage may be read.
+    Frag a0[4], b0[NT], a1[4], b1[NT];
+    read_frags(0, 0, a0, b0);
+    int buf = 0;
+    for (;;) {
+        for (int k = 0; k < nk; ++k) {
+            const int sbuf = buf >= 1 ? buf - 1 : 2;      // (buf + 2) % 3: read during the previous K-step
+            const int nbuf = buf == 2 ? 0 : buf + 1;
+            const bool issue = s_more;
+            const bool last = k == nk - 1;
+            read_frags(buf, 1, a1, b1);
+            if (issue) stage_a(sbuf);
+            mma(a0, b0);
+            // the stage read next was issued during the previous K-step: only this K-step's
+            // pixel loads may stay in flight; every LDS read issued so far has long returned
+            if (issue) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!last || cur + rstep < row_tiles) read_frags(nbuf, 0, a0, b0);
+            if (issue) {
+                stage_b(sbuf);
+                staged();
+            }
+            mma(a1, b1);
+            if (last) {
+                write_tile(cur);
+                init_acc();
+            }
+            buf = nbuf;
+        }
+        cur += rstep;
+        if (cur >= row_tiles) break;
+    }
+
+    if constexpr (STATS) {
+        // per-lane sums -> the 16 pixel lanes of each group -> the four pixel waves, through LDS
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s1[e] += __shfl_xor(s1[e], o, 64);
+                s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+        }
+        __syncthreads();                                  // every wave is done with the staged tiles
+        float* red = reinterpret_cast<float*>(smem);      // [wm][BN channels of the tile][2]
+        if (frow == 0) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                const int col = wn * (BN / 2) + fgrp * CPL + e;
+                red[(wm * BN + col) * 2 + 0] = s1[e];
+                red[(wm * BN + col) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        const int part = bid / n_tiles;
+        for (int idx = tid; idx < BN * 2; idx += 512) {
+            const int col = idx >> 1;
+            if (n0 + col < N)
+                ep.stats[((int64_t)part * N + n0 + col) * 2 + (idx & 1)] =
+                    (red[idx] + red[BN * 2 + idx]) + (red[2 * BN * 2 + idx] + red[3 * BN * 2 + idx]);
         }
     }
 }
@@ -1079,6 +1435,15 @@ static bool nt_classic() {
     return v;
 }
 
+// The 256-row kernel serves wide-channel layers with at least two tiles per CU; VAMD_NT_WIDE=0/1
+// forces the choice (1: wherever the shape allows) for side-by-side measurements.
+static bool nt_wide(int BN, int64_t M, int batch, int n_tiles) {
+    static const int force = [] { const char* e = getenv("VAMD_NT_WIDE"); return e ? atoi(e) : -1; }();
+    if (BN != 128 || nt_classic() || force == 0) return false;
+    const int64_t tiles = ((M + 255) / 256) * batch * n_tiles;
+    return force == 1 ? tiles >= 1 : tiles >= 512;
+}
+
 template <typename T, int BN, bool UP>
 static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
                      void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
@@ -1098,6 +1463,30 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
                            m_tiles, n_tiles, sA, sB, sC);
         VAMD_LAUNCH_OK("conv_nt_mfma");
         return 0;
+    }
+    if constexpr (BN == 128) {
+        if (nt_wide(BN, gp.M, batch, n_tiles)) {
+            constexpr int LDS_W = 3 * (256 * kRowBytes + BN * kRowBytes);
+            static bool configured_w = false;
+            if (!configured_w) {
+                int rc = set_lds_limit(conv_ntw_mfma_kernel<T, BN, UP, false>, LDS_W, "conv_ntw_mfma");
+                if (!rc) rc = set_lds_limit(conv_ntw_mfma_kernel<T, BN, UP, true>, LDS_W, "conv_ntw_mfma");
+                if (rc) return rc;
+                configured_w = true;
+            }
+            const int mw_tiles = (gp.M + 255) / 256;
+            const int row_tiles = mw_tiles * batch;
+            const int groups = ntp_row_groups(row_tiles, n_tiles, 1);
+            TimedLaunch timed(TIMED_NT, 2.0 * gp.M * N * gp.Ktot * batch, st);
+            if (ep.stats)
+                hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, true>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp,
+                                   x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
+            else
+                hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, false>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp,
+                                   x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
+            VAMD_LAUNCH_OK("conv_ntw_mfma");
+            return 0;
+        }
     }
     static bool configured_p = false;
     if (!configured_p) {
@@ -1138,7 +1527,9 @@ int conv_fwd_mfma_stats_parts(const ConvGeom& g) {
     const int m_tiles = (int)((g.M + kBM - 1) / kBM);
     if (nt_classic()) return m_tiles;
     const int BN = g.Cout <= 64 ? 64 : 128;               // as run_nt picks
-    return ntp_row_groups(m_tiles, (g.Cout + BN - 1) / BN, ntp_per_cu(BN));
+    const int n_tiles = (g.Cout + BN - 1) / BN;
+    if (nt_wide(BN, g.M, 1, n_tiles)) return ntp_row_groups((int)((g.M + 255) / 256), n_tiles, 1);
+    return ntp_row_groups(m_tiles, n_tiles, ntp_per_cu(BN));
 }
 
 int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
