@@ -1152,14 +1152,13 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     }
     int mleft = gp.M - step0 * KP;                         // rows of the current K-step below this are real pixels
     const int sshift = gp.stride - 1;
-    const T* zero = reinterpret_cast<const T*>(g_zero_page);
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy), rxg = make_rsrc(x);
 
     auto stage_a = [&](int buf) {
         unsigned char* sa = smem + buf * STAGE + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < NPASS_A; ++i) {
-            const T* src = pick_ptr(a_row[i] < mleft, dy + (uint32_t)a_off[i], zero);
-            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sa + i * 4096), 16, 0, 0);
+            load16_lds(rdy, (uint32_t)a_off[i] * (uint32_t)sizeof(T), a_row[i] < mleft, sa + i * 4096);
             a_off[i] += KP * lda;
         }
     };
@@ -1172,8 +1171,7 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
             const bool ok = (b_row[i] < mleft) & ((unsigned)u < (unsigned)gp.He) & ((unsigned)v < (unsigned)gp.We);
             const uint32_t pix = __umul24(__umul24((uint32_t)b_img[i], (uint32_t)gp.Hin) + (uint32_t)(u >> gp.shift), (uint32_t)gp.Win) +
                                  (uint32_t)(v >> gp.shift);
-            const T* src = pick_ptr(ok, x + (pix * (uint32_t)gp.ldx + (uint32_t)b_c[i]), zero);
-            __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sb + i * 4096), 16, 0, 0);
+            load16_lds(rxg, (pix * (uint32_t)gp.ldx + (uint32_t)b_c[i]) * (uint32_t)sizeof(T), ok, sb + i * 4096);
             // advance this pass by KP pixels
             int wo = b_wo[i] + kr_w;
             const int cw = wo >= gp.Wo ? 1 : 0;
@@ -1435,13 +1433,13 @@ static bool nt_classic() {
     return v;
 }
 
-// The 256-row kernel serves wide-channel layers with at least two tiles per CU; VAMD_NT_WIDE=0/1
-// forces the choice (1: wherever the shape allows) for side-by-side measurements.
+// The 256-row kernel serves wide-channel layers from VAMD_NT_WIDE_MIN tiles on; VAMD_NT_WIDE=0
+// switches it off (side-by-side measurements).
 static bool nt_wide(int BN, int64_t M, int batch, int n_tiles) {
     static const int force = [] { const char* e = getenv("VAMD_NT_WIDE"); return e ? atoi(e) : -1; }();
+    static const int min_tiles = [] { const char* e = getenv("VAMD_NT_WIDE_MIN"); return e ? atoi(e) : 1; }();
     if (BN != 128 || nt_classic() || force == 0) return false;
-    const int64_t tiles = ((M + 255) / 256) * batch * n_tiles;
-    return force == 1 ? tiles >= 1 : tiles >= 512;
+    return ((M + 255) / 256) * batch * n_tiles >= min_tiles;
 }
 
 template <typename T, int BN, bool UP>
