@@ -115,9 +115,12 @@ def main():
     local_rank = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # VAMD_DP_FORCE=1 with WORLD_SIZE=1 (under torch.distributed.run): a one-rank process group, so
+    # that the exchange path runs through RCCL on a one-GPU machine
+    grouped = world > 1 or (os.environ.get("VAMD_DP_FORCE") == "1" and "MASTER_ADDR" in os.environ)
+    if grouped:
         dist.init_process_group(backend)
-    rank = dist.get_rank() if world > 1 else 0
+    rank = dist.get_rank() if grouped else 0
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -159,7 +162,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -181,7 +184,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.profile = None
     lib.vamd_launch_timing(0)
-    if world > 1:
+    if grouped:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -261,7 +264,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -123,3 +123,24 @@ def test_two_ranks_match_single_process(tmp_path):
     perr = (diff.norm() / eng.flat_p.norm()).item()
     assert perr < 2e-3, perr
     assert torch.allclose(r0["bufs"].to(dev), eng.flat_b, rtol=1e-5, atol=1e-6)
+
+
+def test_rccl_path_with_one_rank_group():
+    """bench.py under torch.distributed.run with ONE rank and VAMD_DP_FORCE=1: the parameter / buffer
+    broadcasts and the bucketed asynchronous gradient all-reduce (ReduceOp.AVG) go through RCCL on
+    this GPU, exactly as they do with N ranks; the step must still train (finite loss)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VAMD_DP_FORCE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sampling", "--preset", "flowers",
+           "--batch", "8"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0
+    assert 0.0 < res["final_loss"] < 10.0

@@ -45,6 +45,15 @@ def world_info(group=None):
     return 0, 1
 
 
+def collectives_on(world: int) -> bool:
+    """Collectives are skipped on a single rank, unless VAMD_DP_FORCE=1 asks for them anyway: a
+    one-rank process group still goes through the backend (RCCL communicator, streams, async
+    handles), which is how the exchange code is rehearsed on a one-GPU machine."""
+    if world > 1:
+        return True
+    return os.environ.get("VAMD_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
+
+
 class GradReducer:
     """Bucketed, overlapped mean all-reduce of a flat gradient arena.
 
@@ -66,7 +75,8 @@ class GradReducer:
         self.buckets = cut                    # tail first, last one starts at 0
         self._next = 0
         self._pending = []
-        backend = dist.get_backend(group) if self.world > 1 else "none"
+        self._on = collectives_on(self.world)
+        backend = dist.get_backend(group) if self._on else "none"
         self._use_avg = backend == "nccl"     # ReduceOp.AVG exists for nccl/RCCL only
         # VAMD_DP_SERIAL=1: blocking collectives (no overlap with backward), for debugging
         self._serial = os.environ.get("VAMD_DP_SERIAL", "0") == "1"
@@ -85,7 +95,7 @@ class GradReducer:
         self.layer_done(0)
 
     def _issue(self, lo, hi):
-        if self.world == 1:
+        if not self._on:
             return
         view = self.flat[lo:hi]
         op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
@@ -133,7 +143,8 @@ class DataParallel:
         self.reducer = GradReducer(eng.flat_g, eng.layer_offsets(), group, bucket_bytes)
         model.grad_reducer = self.reducer
         eng.reducer = self.reducer
-        if self.world > 1:
+        self._on = collectives_on(self.world)
+        if self._on:
             broadcast(eng.flat_p, self._src(), group)       # identical start on every rank
             eng.dirty = True
             self.broadcast_buffers()
@@ -144,7 +155,7 @@ class DataParallel:
     def broadcast_buffers(self):
         """Rank 0's BatchNorm running statistics and counters replace everybody's (two collectives:
         the buffers live in one fp32 and one int64 arena)."""
-        if self.world == 1:
+        if not self._on:
             return
         eng = self.engine
         broadcast(eng.flat_b, self._src(), self.group)
@@ -152,7 +163,7 @@ class DataParallel:
 
     def all_reduce_scalar_mean(self, value: torch.Tensor) -> torch.Tensor:
         """`self.log(..., sync_dist=True)` of the reference (models/ddpm.py:314,327,337)."""
-        if self.world == 1:
+        if not self._on:
             return value
         v = value.detach().clone()
         if _staged(v, self.group):
