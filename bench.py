@@ -79,8 +79,8 @@ def cpu_baseline(seconds_budget=25.0):
                       f"sampling 4 images x 2 steps took {samp:.1f} s = {4 * 2 / samp:.2f} image-steps/s"}
 
 
-def measured_traffic(kernel_substr):
-    """HBM bytes per launch of the kernels whose name contains `kernel_substr`, from the committed
+def measured_traffic(*kernel_substrs):
+    """HBM bytes per launch of the kernels whose name contains one of `kernel_substrs`, from the committed
     counter pass profiles/r1_pmc_tcc_traffic.csv ((2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch,
     same workload); None when the file is missing."""
     import csv
@@ -90,7 +90,7 @@ def measured_traffic(kernel_substr):
     nbytes, launches = 0.0, 0
     with open(path) as f:
         for row in csv.reader(f):
-            if kernel_substr in row[0]:
+            if any(k in row[0] for k in kernel_substrs):
                 nbytes += (2.0 * float(row[2]) + float(row[3])) * 1024.0
                 launches += int(row[1])
     return round(nbytes / launches) if launches else None
@@ -208,10 +208,10 @@ def main():
     if n:
         conv_ms += t
         ach = f / (t * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_ntp_mfma_kernel<bf16> (persistent implicit-GEMM, forward + input gradient)",
+        roof = {"bound": "mfma", "kernel": "conv_ntw_mfma_kernel / conv_ntp_mfma_kernel <bf16> (persistent implicit-GEMM, forward + input gradient)",
                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                "traffic": measured_traffic("conv_ntp_mfma_kernel") if args.preset == "butterfly" and B == 64 else None,
+                "traffic": measured_traffic("conv_ntp_mfma_kernel", "conv_ntw_mfma_kernel") if args.preset == "butterfly" and B == 64 else None,
                 "traffic_unit": "HBM bytes per launch (PMC pass of the same command, profiles/r1_pmc_tcc_traffic.csv)",
                 "launches": n, "avg_launch_ms": round(t / n, 5), "flops_per_launch": round(f / n)}
     f, t, n = timed(1)

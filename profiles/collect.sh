@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun -- bash profiles/collect.sh): kernel trace + statistics of the default
+# training bench, then the counter passes (each in a run of its own, counters only).
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/collect
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-sampling"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 10 --warmup 3 > $OUT/trace.log 2>&1
+echo "trace done"
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $BENCH --steps 1 --warmup 1 > $OUT/fetch.log 2>&1
+echo "fetch done"
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $BENCH --steps 1 --warmup 1 > $OUT/write.log 2>&1
+echo "write done"
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/sq -- $BENCH --steps 1 --warmup 1 > $OUT/sq.log 2>&1
+echo "sq done"

@@ -1,0 +1,52 @@
+"""Turns gpurun_out/collect (written by profiles/collect.sh) into the committed summaries:
+r1_train_step_kernel_stats.csv, r1_train_step_bench_line.json, r1_pmc_tcc_traffic.csv, r1_pmc_sq_summary.csv."""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "gpurun_out", "collect")
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(SRC, pattern))
+    assert hits, pattern
+    return hits[0]
+
+
+def counters(sub):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(set)
+    for r in csv.DictReader(open(one(f"{sub}/*/*_counter_collection.csv"))):
+        agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[r["Kernel_Name"]].add(r["Dispatch_Id"])
+    return agg, {k: len(v) for k, v in launches.items()}
+
+
+shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(HERE, "r1_train_step_kernel_stats.csv"))
+line = [ln for ln in open(os.path.join(SRC, "trace.log")) if ln.startswith("{")][-1]
+open(os.path.join(HERE, "r1_train_step_bench_line.json"), "w").write(line)
+
+fetch, nf = counters("fetch")
+write, _ = counters("write")
+with open(os.path.join(HERE, "r1_pmc_tcc_traffic.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "launches", "FETCH_SIZE_KB_sum", "WRITE_SIZE_KB_sum", "hbm_bytes_per_launch(2*FETCH+WRITE)*1024"])
+    rows = []
+    for k in fetch:
+        fs, ws, n = fetch[k]["FETCH_SIZE"], write.get(k, {}).get("WRITE_SIZE", 0.0), nf[k]
+        rows.append((k, n, round(fs), round(ws), round((2 * fs + ws) * 1024 / n)))
+    for row in sorted(rows, key=lambda r: -r[1] * r[4]):
+        w.writerow(row)
+
+sq, ns = counters("sq")
+names = sorted({c for v in sq.values() for c in v})
+with open(os.path.join(HERE, "r1_pmc_sq_summary.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "launches"] + names)
+    for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+        w.writerow([k, ns[k]] + [round(v.get(c, 0.0)) for c in names])
+print("wrote summaries from", SRC)
