@@ -144,7 +144,7 @@ thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __re
 // --------------------------------------------------------------------------------- thin_out
 // Wave = one strip of 16 pixels x R rows of one image.  Cin = 32 * NH, Cout <= 16.
 template <int K, int NH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 thin_out_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                      const float* __restrict__ bias, const float* __restrict__ temb,
                      const bf16_t* __restrict__ res, const bf16_t* __restrict__ res2, bf16_t* __restrict__ y,
@@ -189,9 +189,37 @@ thin_out_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __r
     for (int i = 0; i < K; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int hi_first = h0 - g.pad, hi_last = h1 - 1 + (K - 1 - g.pad);
     bf16x8_t cur[K][NH], nxt[K][NH];
+    // per-lane epilogue constants (D row = output channel 4*grp + r): loads inside the row loop would
+    // be younger than the next row's prefetch, and waiting for them would wait for the prefetch too
+    float bt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = 4 * grp + r;
+        bt[r] = 0.f;
+        if (co < g.Cout) {
+            if (bias) bt[r] += bias[co];
+            if (temb) bt[r] += temb[(int64_t)b * g.Cout + co];
+        }
+    }
     load_row(hi_first, cur);
 #pragma unroll 1
     for (int hi = hi_first; hi <= hi_last; ++hi) {
+        const int hout = hi + g.pad - (K - 1);                 // the output row completed by input row hi
+        const int wq = w0 + p;
+        const bool store = hout >= h0 && hout < h1 && wq < g.W;
+        const int64_t m = ((int64_t)b * g.H + hout) * g.W + wq;
+        // residual operands of that row first, then the next input row: loads return in order
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (store && (res || res2)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * grp + r;
+                if (co < g.Cout) {
+                    if (res) rv[r] += to_f(res[m * g.Cout + co]);
+                    if (res2) rv[r] += to_f(res2[m * g.Cout + co]);
+                }
+            }
+        }
         if (hi < hi_last) load_row(hi + 1, nxt);
         // input row hi feeds output row hi + pad - r through filter row r; slot i = K-1-r holds
         // output row hi + pad - (K-1) + i
@@ -202,21 +230,11 @@ thin_out_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __r
 #pragma unroll
                 for (int hf = 0; hf < NH; ++hf)
                     acc[K - 1 - r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r * K + s][hf], cur[s][hf], acc[K - 1 - r], 0, 0, 0);
-        const int hout = hi + g.pad - (K - 1);                 // slot 0 is complete
-        const int wq = w0 + p;
-        if (hout >= h0 && hout < h1 && wq < g.W) {
-            const int64_t m = ((int64_t)b * g.H + hout) * g.W + wq;
+        if (store) {                                           // slot 0 is complete
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = 4 * grp + r;                    // D row = output channel
-                if (co < g.Cout) {
-                    float v = acc[0][r];
-                    if (bias) v += bias[co];
-                    if (temb) v += temb[(int64_t)b * g.Cout + co];
-                    if (res) v += to_f(res[m * g.Cout + co]);
-                    if (res2) v += to_f(res2[m * g.Cout + co]);
-                    y[m * g.Cout + co] = from_f<bf16_t>(v);
-                }
+                if (co < g.Cout) y[m * g.Cout + co] = from_f<bf16_t>(acc[0][r] + bt[r] + rv[r]);
             }
         }
 #pragma unroll
