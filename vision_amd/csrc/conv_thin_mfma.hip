@@ -38,35 +38,21 @@ __device__ __forceinline__ bf16x8_t zero8() {
 }
 
 // ---------------------------------------------------------------------------------- thin_in
-// Block = one 16x16 pixel tile of one image, 4 waves x 4 tile rows.  Cout = 16 * NTN.
+// Block = kThinInTiles consecutive 16x16 pixel tiles, 4 waves x 4 tile rows each.  Cout = 16 * NTN.
+// The filter fragments and the per-channel epilogue constants stay in registers across the tiles.
+constexpr int kThinInTiles = 4;
+
 template <int K, int NTN>
 __global__ void __launch_bounds__(256)
 thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                     const float* __restrict__ bias, const float* __restrict__ temb,
                     const bf16_t* __restrict__ res, const bf16_t* __restrict__ res2, bf16_t* __restrict__ y,
-                    int tiles_w, int tiles_h) {
+                    int tiles_w, int tiles_h, int ntiles) {
     constexpr int HT = 16 + K - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);          // [HT][HT][Cin], zero outside the image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int tx = bid % tiles_w;
-    bid /= tiles_w;
-    const int ty = bid % tiles_h;
-    const int b = bid / tiles_h;
-    const int h0 = ty * 16, w0 = tx * 16;
     const int Cin = g.Cin, Ktot = K * K * Cin, Cout = 16 * NTN;
-
-    const int total = HT * HT * Cin;
-    for (int e = tid; e < total; e += 256) {
-        const int c = e % Cin, pp = e / Cin;
-        const int xx = pp % HT, yy = pp / HT;
-        const int hi = h0 + yy - g.pad, wi = w0 + xx - g.pad;
-        bf16_t v = (bf16_t)0.f;
-        if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
-            v = x[(((int64_t)b * g.H + hi) * g.W + wi) * Cin + c];
-        halo[e] = v;
-    }
 
     // A = filter, rows permuted: MFMA jt, row i  <->  output channel (i>>2)*(4*NTN) + 4*jt + (i&3),
     // so that the 4*NTN accumulators of a lane are consecutive channels
@@ -89,53 +75,78 @@ thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __re
             afrag[jt][j] = k < Ktot ? w[(int64_t)co * Ktot + k] : (bf16_t)0.f;
         }
     }
-    __syncthreads();
+    const int c0 = grp * 4 * NTN;             // this lane's output channels: c0 .. c0 + 4*NTN - 1
+    float bch[4 * NTN];
+#pragma unroll
+    for (int e = 0; e < 4 * NTN; ++e) bch[e] = bias ? bias[c0 + e] : 0.f;
+
+    const int total = HT * HT * Cin;
+    const int t_end = min((int)(blockIdx.x + 1) * kThinInTiles, ntiles);
+    int b_prev = -1;
+    f32x4_t init[NTN];
+#pragma unroll 1
+    for (int tile = blockIdx.x * kThinInTiles; tile < t_end; ++tile) {
+        const int tx = tile % tiles_w;
+        const int ty = (tile / tiles_w) % tiles_h;
+        const int b = tile / (tiles_w * tiles_h);
+        const int h0 = ty * 16, w0 = tx * 16;
+        if (b != b_prev) {                    // accumulators start from bias + time embedding of the image
+#pragma unroll
+            for (int jt = 0; jt < NTN; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    init[jt][r] = bch[4 * jt + r] + (temb ? temb[(int64_t)b * Cout + c0 + 4 * jt + r] : 0.f);
+            b_prev = b;
+        }
+        __syncthreads();                      // the previous tile's halo has been read by every wave
+        for (int e = tid; e < total; e += 256) {
+            const int c = e % Cin, pp = e / Cin;
+            const int xx = pp % HT, yy = pp / HT;
+            const int hi = h0 + yy - g.pad, wi = w0 + xx - g.pad;
+            bf16_t v = (bf16_t)0.f;
+            if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+                v = x[(((int64_t)b * g.H + hi) * g.W + wi) * Cin + c];
+            halo[e] = v;
+        }
+        __syncthreads();
 
 #pragma unroll 1
-    for (int rr = 0; rr < 4; ++rr) {
-        const int tyy = wave * 4 + rr;
-        const int h = h0 + tyy;
-        if (h >= g.H) break;                  // wave-uniform
-        const int base = (tyy * HT + p) * Cin;
-        bf16x8_t bfrag;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int tyy = wave * 4 + rr;
+            const int h = h0 + tyy;
+            if (h >= g.H) break;                  // wave-uniform
+            const int base = (tyy * HT + p) * Cin;
+            bf16x8_t bfrag;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bfrag[j] = halo[base + off[j]];
-        f32x4_t acc[NTN];
+            for (int j = 0; j < 8; ++j) bfrag[j] = halo[base + off[j]];
+            f32x4_t acc[NTN];
 #pragma unroll
-        for (int jt = 0; jt < NTN; ++jt)
-            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[jt], bfrag, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const int wq = w0 + p;
-        if (wq < g.W) {
-            const int64_t m = ((int64_t)b * g.H + h) * g.W + wq;
-            const int c0 = grp * 4 * NTN;
+            for (int jt = 0; jt < NTN; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[jt], bfrag, init[jt], 0, 0, 0);
+            const int wq = w0 + p;
+            if (wq < g.W) {
+                const int64_t m = ((int64_t)b * g.H + h) * g.W + wq;
 #pragma unroll
-            for (int ch = 0; ch < NTN / 2; ++ch) {            // chunks of 8 channels = 16 bytes
-                float v[8];
+                for (int ch = 0; ch < NTN / 2; ++ch) {            // chunks of 8 channels = 16 bytes
+                    float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[ch * 2 + (e >> 2)][e & 3];
-                const int cc = c0 + ch * 8;
-                if (bias) {
+                    for (int e = 0; e < 8; ++e) v[e] = acc[ch * 2 + (e >> 2)][e & 3];
+                    const int cc = c0 + ch * 8;
+                    if (res) {
+                        const Vec16<bf16_t> rv = *reinterpret_cast<const Vec16<bf16_t>*>(res + m * Cout + cc);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bias[cc + e];
+                        for (int e = 0; e < 8; ++e) v[e] += to_f(rv.v[e]);
+                    }
+                    if (res2) {
+                        const Vec16<bf16_t> rv = *reinterpret_cast<const Vec16<bf16_t>*>(res2 + m * Cout + cc);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += to_f(rv.v[e]);
+                    }
+                    Vec16<bf16_t> ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov.v[e] = from_f<bf16_t>(v[e]);
+                    *reinterpret_cast<Vec16<bf16_t>*>(y + m * Cout + cc) = ov;
                 }
-                if (temb) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += temb[(int64_t)b * Cout + cc + e];
-                }
-                if (res) {
-                    const Vec16<bf16_t> rv = *reinterpret_cast<const Vec16<bf16_t>*>(res + m * Cout + cc);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += to_f(rv.v[e]);
-                }
-                if (res2) {
-                    const Vec16<bf16_t> rv = *reinterpret_cast<const Vec16<bf16_t>*>(res2 + m * Cout + cc);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += to_f(rv.v[e]);
-                }
-                Vec16<bf16_t> ov;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ov.v[e] = from_f<bf16_t>(v[e]);
-                *reinterpret_cast<Vec16<bf16_t>*>(y + m * Cout + cc) = ov;
             }
         }
     }
@@ -488,9 +499,10 @@ static void launch_thin_in(const ConvGeom& g, const void* x, const void* w, cons
     const int tw = (g.W + 15) / 16, th = (g.H + 15) / 16;
     constexpr int HT = 16 + K - 1;
     const size_t lds = (size_t)HT * HT * g.Cin * 2;
-    hipLaunchKernelGGL((thin_in_mfma_kernel<K, NTN>), dim3((unsigned)(g.B * th * tw)), dim3(256), lds, st, g,
-                       (const bf16_t*)x, (const bf16_t*)w, bias, temb, (const bf16_t*)res, (const bf16_t*)res2,
-                       (bf16_t*)y, tw, th);
+    const int ntiles = g.B * th * tw;
+    hipLaunchKernelGGL((thin_in_mfma_kernel<K, NTN>), dim3((unsigned)((ntiles + kThinInTiles - 1) / kThinInTiles)), dim3(256),
+                       lds, st, g, (const bf16_t*)x, (const bf16_t*)w, bias, temb, (const bf16_t*)res,
+                       (const bf16_t*)res2, (bf16_t*)y, tw, th, ntiles);
 }
 
 int thin_in_mfma(const ConvGeom& g, const void* x, const void* w, const float* bias, const float* temb,
