@@ -18,6 +18,10 @@
 
 #include "conv_shapes.h"
 
+#ifndef VAMD_ABLATE
+#define VAMD_ABLATE 0        // 1..4: timing-only experiments on the wide kernel (results are wrong)
+#endif
+
 namespace vamd {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -999,16 +1003,26 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             const bool issue = s_more;
             const bool last = k == nk - 1;
             read_frags(buf, 1, a1, b1);
+#if VAMD_ABLATE != 4
             if (issue) stage_a(sbuf);
+#endif
             mma(a0, b0);
             // the stage read next was issued during the previous K-step: only this K-step's
             // pixel loads may stay in flight; every LDS read issued so far has long returned
+#if VAMD_ABLATE == 1 || VAMD_ABLATE == 3
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
             if (issue) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+#if VAMD_ABLATE != 2 && VAMD_ABLATE != 3
             __builtin_amdgcn_s_barrier();
+#endif
             if (!last || cur + rstep < row_tiles) read_frags(nbuf, 0, a0, b0);
             if (issue) {
+#if VAMD_ABLATE != 4
                 stage_b(sbuf);
+#endif
                 staged();
             }
             mma(a1, b1);
