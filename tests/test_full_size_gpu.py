@@ -120,8 +120,10 @@ def test_full_size_conv_layers(case):
         assert torch.equal(dxq, dx[sl]), f"input gradient of images {i * q}..{(i + 1) * q} depends on the batch"
         dw_sum += dwq.double()
         db_sum += dbq.double()
-    assert relerr(dw, dw_sum) < 2e-6
-    assert relerr(db, db_sum) < 2e-6
+    # fp32 sums in a different association; the thin-channel layers add their bias-gradient block
+    # partials with atomics, so that one also moves from run to run
+    assert relerr(dw, dw_sum) < 1e-5
+    assert relerr(db, db_sum) < 1e-5
 
     # the last image against an fp64 CPU convolution
     xl = x[-1:].permute(0, 3, 1, 2).double().cpu().requires_grad_(True)

@@ -77,6 +77,10 @@ CONV_CASES = [
     (3, 9, 7, 32, 64, 3, 1, 0),
     (2, 10, 10, 64, 32, 3, 1, 0),
     (1, 13, 11, 128, 192, 3, 1, 0),
+    (1, 20, 26, 256, 256, 3, 1, 0),
+    (1, 9, 11, 256, 256, 3, 1, 1),
+    (2, 18, 18, 256, 512, 1, 1, 0),
+    (1, 18, 22, 256, 256, 3, 2, 0),
     (2, 12, 12, 64, 64, 3, 2, 0),
     (2, 7, 9, 32, 32, 3, 2, 0),
     (2, 6, 5, 64, 64, 3, 1, 1),

@@ -980,6 +980,37 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     stage_a(0);
     stage_b(0);
     staged();
+    if constexpr (BN == 256) {
+        // 256 x 256 tile (wave tile 64 x 128, 128 accumulator registers): two stages, the next K-step's
+        // loads issued at the start of this one, fragments read per half K-step, one barrier at the end
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int buf = 0;
+        for (;;) {
+            for (int k = 0; k < nk; ++k) {
+                const bool issue = s_more;
+                Frag fa[4], fb[NT];
+                read_frags(buf, 0, fa, fb);
+                if (issue) stage_a(buf ^ 1);
+                mma(fa, fb);
+                read_frags(buf, 1, fa, fb);
+                if (issue) {
+                    stage_b(buf ^ 1);
+                    staged();
+                }
+                mma(fa, fb);
+                if (k == nk - 1) {
+                    write_tile(cur);
+                    init_acc();
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                buf ^= 1;
+            }
+            cur += rstep;
+            if (cur >= row_tiles) break;
+        }
+    } else {
     if (s_more) {
         stage_a(1);
         stage_b(1);
@@ -1036,6 +1067,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         if (cur >= row_tiles) break;
     }
 
+    }
     if constexpr (STATS) {
         // per-lane sums -> the 16 pixel lanes of each group -> the four pixel waves, through LDS
 #pragma unroll
@@ -1520,9 +1552,44 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
     return 0;
 }
 
+// 256 x 256 tiles for bf16 layers with a multiple of 256 output channels and no fused statistics
+// (the statistics would need 64 more registers per lane); VAMD_NT_WIDE256=0 switches it off.
+static bool nt_wide256(int N, int64_t M, int batch, bool stats, size_t elem) {
+    static const int on = [] { const char* e = getenv("VAMD_NT_WIDE256"); return e ? atoi(e) : 1; }();
+    static const int min_tiles = [] { const char* e = getenv("VAMD_NT_WIDE256_MIN"); return e ? atoi(e) : 160; }();
+    if (!on || stats || elem != 2 || N % 256 != 0 || nt_classic()) return false;
+    return ((M + 255) / 256) * batch * (N / 256) >= min_tiles;
+}
+
+template <typename T, bool UP>
+static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
+                         void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
+    constexpr int LDS_W = 2 * (256 * kRowBytes + 256 * kRowBytes);
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds_limit(conv_ntw_mfma_kernel<T, 256, UP, false>, LDS_W, "conv_ntw_mfma");
+        if (rc) return rc;
+        configured = true;
+    }
+    const int n_tiles = N / 256, mw_tiles = (gp.M + 255) / 256;
+    const int row_tiles = mw_tiles * batch;
+    const int groups = ntp_row_groups(row_tiles, n_tiles, 1);
+    TimedLaunch timed(TIMED_NT, 2.0 * gp.M * N * gp.Ktot * batch, st);
+    hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, 256, UP, false>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp, x, w, N,
+                       ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
+    VAMD_LAUNCH_OK("conv_ntw_mfma");
+    return 0;
+}
+
 template <typename T>
 static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep,
                   void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (nt_wide256(N, gp.M, batch, ep.stats != nullptr, sizeof(T))) {
+            if (gp.shift) return launch_ntw256<T, true>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+            return launch_ntw256<T, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+        }
+    }
     if (gp.shift) {
         if (N <= 64) return launch_nt<T, 64, true>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
         return launch_nt<T, 128, true>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
