@@ -132,7 +132,7 @@ int vamd_conv2d_stats_parts(const vamd_conv_desc* d) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_stats_parts")) return 0;
     const int a = pick(d->algo, conv_thin_supported(g, d->dtype), conv_fwd_mfma_supported(g, d->dtype), "", g);
-    return a == kMfma ? conv_fwd_mfma_stats_parts(g) : 0;
+    return a == kMfma ? conv_fwd_mfma_stats_parts(g, d->dtype) : 0;
 }
 
 int vamd_conv2d_uses_mfma(const vamd_conv_desc* d, int pass) {

@@ -861,9 +861,19 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     };
     // ---- outputs: lane (p = lane & 15, grp = lane >> 4) holds, per pixel tile, channels nb .. nb+CPL-1
     const int nb = n0 + wn * (BN / 2) + fgrp * CPL;
-    float s1[STATS ? CPL : 1], s2[STATS ? CPL : 1];
+    // Fused statistics: per-lane sums in registers, except for the 256-channel tile, whose 128
+    // accumulators leave no room for 64 more: there every (pixel-wave row, channel) owns a slot
+    // pair in LDS behind the stages, updated once per tile by the one lane that holds the
+    // 16-lane sum (a fixed order of additions, no atomics).
+    constexpr bool STATS_LDS = STATS && BN == 256;
+    constexpr bool STATS_REG = STATS && !STATS_LDS;
+    float* sred = reinterpret_cast<float*>(smem + (BN == 256 ? 2 : 3) * STAGE);      // [4][BN][2]
+    if constexpr (STATS_LDS) {
+        for (int idx = tid; idx < 4 * BN * 2; idx += 512) sred[idx] = 0.f;            // a barrier follows before any tile is written
+    }
+    float s1[STATS_REG ? CPL : 1], s2[STATS_REG ? CPL : 1];
 #pragma unroll
-    for (int e = 0; e < (STATS ? CPL : 1); ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (int e = 0; e < (STATS_REG ? CPL : 1); ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     // accumulators start from the bias (alpha is 1 whenever a bias is given)
     auto init_acc = [&]() {
 #pragma unroll
@@ -950,13 +960,91 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
 #pragma unroll
                 for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(v[e]);
                 *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + off + ch) = ov;
-                if constexpr (STATS) {                    // statistics of the rounded values a later pass would read
+                if constexpr (STATS_REG) {                // statistics of the rounded values a later pass would read
 #pragma unroll
                     for (int e = 0; e < CH; ++e) {
                         const float q = to_f(ov.v[e]);
                         s1[ch + e] += q;
                         s2[ch + e] = fmaf(q, q, s2[ch + e]);
                     }
+                }
+            }
+        }
+    };
+
+    // the same outputs with the channel piece as the outer loop, so that only 2 x CH sums are live
+    auto write_tile_stats_lds = [&](int row_tile) {
+        const int z = row_tile / m_tiles, mt = row_tile - z * m_tiles;
+        const T* res = reinterpret_cast<const T*>(ep.res);
+        const T* res2 = reinterpret_cast<const T*>(ep.res2);
+        constexpr int CH = 16 / (int)sizeof(T);
+        int64_t offs[4];
+        uint32_t bimgs[4];
+        bool valid[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t m = mt * BM + wm * 64 + i * 16 + frow;
+            valid[i] = m < (uint32_t)gp.M;
+            bimgs[i] = ep.temb ? fdiv(m, gp.div_howo) : 0u;
+            offs[i] = (int64_t)z * strideC + (int64_t)m * ldc + nb;
+        }
+#pragma unroll
+        for (int ch = 0; ch < CPL; ch += CH) {
+            const int n = nb + ch;
+            float t1[CH], t2[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+            if (n < N && n + CH <= ldc) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!valid[i]) continue;
+                    float v[CH];
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) v[e] = acc[(ch + e) >> 2][i][e & 3] * ep.alpha;
+                    if (ep.temb) {
+                        const float* tp = ep.temb + (int64_t)bimgs[i] * N + n;
+#pragma unroll
+                        for (int e = 0; e < CH; e += 4) {
+                            const float4 t4 = *reinterpret_cast<const float4*>(tp + e);
+                            v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
+                        }
+                    }
+                    if (res) {
+                        const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res + offs[i] + ch);
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
+                    }
+                    if (res2) {
+                        const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res2 + offs[i] + ch);
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
+                    }
+                    Vec16<T> ov;
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(v[e]);
+                    *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + offs[i] + ch) = ov;
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) {
+                        const float q = to_f(ov.v[e]);
+                        t1[e] += q;
+                        t2[e] = fmaf(q, q, t2[e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    t1[e] += __shfl_xor(t1[e], o, 64);
+                    t2[e] += __shfl_xor(t2[e], o, 64);
+                }
+            }
+            if (frow == 0) {
+                float* slot = sred + ((wm * BN) + wn * (BN / 2) + fgrp * CPL + ch) * 2;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    slot[2 * e] += t1[e];
+                    slot[2 * e + 1] += t2[e];
                 }
             }
         }
@@ -1000,7 +1088,8 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
                 }
                 mma(fa, fb);
                 if (k == nk - 1) {
-                    write_tile(cur);
+                    if constexpr (STATS_LDS) write_tile_stats_lds(cur);
+                    else write_tile(cur);
                     init_acc();
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1068,7 +1157,17 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     }
 
     }
-    if constexpr (STATS) {
+    if constexpr (STATS_LDS) {
+        __syncthreads();                                  // every wave's slot updates are visible
+        const int part = bid / n_tiles;
+        for (int idx = tid; idx < BN * 2; idx += 512) {
+            const int col = idx >> 1;
+            if (n0 + col < N)
+                ep.stats[((int64_t)part * N + n0 + col) * 2 + (idx & 1)] =
+                    (sred[idx] + sred[BN * 2 + idx]) + (sred[2 * BN * 2 + idx] + sred[3 * BN * 2 + idx]);
+        }
+    }
+    if constexpr (STATS_REG) {
         // per-lane sums -> the 16 pixel lanes of each group -> the four pixel waves, through LDS
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
@@ -1552,22 +1651,22 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
     return 0;
 }
 
-// 256 x 256 tiles for bf16 layers with a multiple of 256 output channels and no fused statistics
-// (the statistics would need 64 more registers per lane); VAMD_NT_WIDE256=0 switches it off.
-static bool nt_wide256(int N, int64_t M, int batch, bool stats, size_t elem) {
+// 256 x 256 tiles for bf16 layers with a multiple of 256 output channels; VAMD_NT_WIDE256=0 switches it off.
+static bool nt_wide256(int N, int64_t M, int batch, size_t elem) {
     static const int on = [] { const char* e = getenv("VAMD_NT_WIDE256"); return e ? atoi(e) : 1; }();
     static const int min_tiles = [] { const char* e = getenv("VAMD_NT_WIDE256_MIN"); return e ? atoi(e) : 160; }();
-    if (!on || stats || elem != 2 || N % 256 != 0 || nt_classic()) return false;
+    if (!on || elem != 2 || N % 256 != 0 || nt_classic()) return false;
     return ((M + 255) / 256) * batch * (N / 256) >= min_tiles;
 }
 
 template <typename T, bool UP>
 static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
                          void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
-    constexpr int LDS_W = 2 * (256 * kRowBytes + 256 * kRowBytes);
+    constexpr int LDS_W = 2 * (256 * kRowBytes + 256 * kRowBytes) + 4 * 256 * 2 * (int)sizeof(float);   // stages + statistics slots
     static bool configured = false;
     if (!configured) {
         int rc = set_lds_limit(conv_ntw_mfma_kernel<T, 256, UP, false>, LDS_W, "conv_ntw_mfma");
+        if (!rc) rc = set_lds_limit(conv_ntw_mfma_kernel<T, 256, UP, true>, LDS_W, "conv_ntw_mfma");
         if (rc) return rc;
         configured = true;
     }
@@ -1575,8 +1674,12 @@ static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ld
     const int row_tiles = mw_tiles * batch;
     const int groups = ntp_row_groups(row_tiles, n_tiles, 1);
     TimedLaunch timed(TIMED_NT, 2.0 * gp.M * N * gp.Ktot * batch, st);
-    hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, 256, UP, false>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp, x, w, N,
-                       ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
+    if (ep.stats)
+        hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, 256, UP, true>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp, x, w, N,
+                           ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
+    else
+        hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, 256, UP, false>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp, x, w, N,
+                           ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
     VAMD_LAUNCH_OK("conv_ntw_mfma");
     return 0;
 }
@@ -1585,7 +1688,7 @@ template <typename T>
 static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep,
                   void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
-        if (nt_wide256(N, gp.M, batch, ep.stats != nullptr, sizeof(T))) {
+        if (nt_wide256(N, gp.M, batch, sizeof(T))) {
             if (gp.shift) return launch_ntw256<T, true>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
             return launch_ntw256<T, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
         }
@@ -1602,9 +1705,10 @@ bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype) {
     return nt_shape_ok(g.Cin, g.Cout, g.M, dtype);
 }
 
-int conv_fwd_mfma_stats_parts(const ConvGeom& g) {
+int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype) {
     const int m_tiles = (int)((g.M + kBM - 1) / kBM);
     if (nt_classic()) return m_tiles;
+    if (dtype == VAMD_BF16 && nt_wide256(g.Cout, g.M, 1, 2)) return ntp_row_groups((int)((g.M + 255) / 256), g.Cout / 256, 1);
     const int BN = g.Cout <= 64 ? 64 : 128;               // as run_nt picks
     const int n_tiles = (g.Cout + BN - 1) / BN;
     if (nt_wide(BN, g.M, 1, n_tiles)) return ntp_row_groups((int)((g.M + 255) / 256), n_tiles, 1);

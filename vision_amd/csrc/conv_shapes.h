@@ -49,7 +49,7 @@ int thin_wgrad_mfma(const ConvGeom& g, const void* dy, const void* x, float* dw,
 bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype);
 int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
                   const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st);
-int conv_fwd_mfma_stats_parts(const ConvGeom& g);      // row tiles = leading extent of `stats`
+int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype);      // row tiles = leading extent of `stats`
 bool conv_dgrad_mfma_supported(const ConvGeom& g, int dtype);
 size_t conv_dgrad_mfma_workspace(const ConvGeom& g, int dtype);
 int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt, const void* add,
