@@ -12,9 +12,9 @@ SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "gpurun_out
 
 
 def one(pattern):
-    hits = glob.glob(os.path.join(SRC, pattern))
+    hits = sorted(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)
     assert hits, pattern
-    return hits[0]
+    return hits[-1]                      # newest: results of earlier collections may still lie beside it
 
 
 def counters(sub):
