@@ -1652,10 +1652,14 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
 }
 
 // 256 x 256 tiles for bf16 layers with a multiple of 256 output channels; VAMD_NT_WIDE256=0 switches it off.
-static bool nt_wide256(int N, int64_t M, int batch, size_t elem) {
+// Measured inside the training step: it pays for long reductions (3x3 over >= 256 channels; with the
+// upsampling gather only from 512 channels on) and >= 160 tiles; VAMD_NT_WIDE256_MIN=1 forces it
+// wherever the shape allows (tests).
+static bool nt_wide256(int N, int64_t M, int batch, size_t elem, int Ktot, bool up) {
     static const int on = [] { const char* e = getenv("VAMD_NT_WIDE256"); return e ? atoi(e) : 1; }();
     static const int min_tiles = [] { const char* e = getenv("VAMD_NT_WIDE256_MIN"); return e ? atoi(e) : 160; }();
     if (!on || elem != 2 || N % 256 != 0 || nt_classic()) return false;
+    if (min_tiles > 1 && Ktot < (up ? 4608 : 2304)) return false;
     return ((M + 255) / 256) * batch * (N / 256) >= min_tiles;
 }
 
@@ -1688,7 +1692,7 @@ template <typename T>
 static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep,
                   void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
-        if (nt_wide256(N, gp.M, batch, sizeof(T))) {
+        if (nt_wide256(N, gp.M, batch, sizeof(T), gp.Ktot, gp.shift != 0)) {
             if (gp.shift) return launch_ntw256<T, true>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
             return launch_ntw256<T, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
         }
@@ -1708,7 +1712,7 @@ bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype) {
 int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype) {
     const int m_tiles = (int)((g.M + kBM - 1) / kBM);
     if (nt_classic()) return m_tiles;
-    if (dtype == VAMD_BF16 && nt_wide256(g.Cout, g.M, 1, 2)) return ntp_row_groups((int)((g.M + 255) / 256), g.Cout / 256, 1);
+    if (dtype == VAMD_BF16 && nt_wide256(g.Cout, g.M, 1, 2, g.k * g.k * g.Cin, g.up != 0)) return ntp_row_groups((int)((g.M + 255) / 256), g.Cout / 256, 1);
     const int BN = g.Cout <= 64 ? 64 : 128;               // as run_nt picks
     const int n_tiles = (g.Cout + BN - 1) / BN;
     if (nt_wide(BN, g.M, 1, n_tiles)) return ntp_row_groups((int)((g.M + 255) / 256), n_tiles, 1);
