@@ -78,6 +78,10 @@ CONV_CASES = [
     (2, 10, 10, 64, 32, 3, 1, 0),
     (1, 13, 11, 128, 192, 3, 1, 0),
     (1, 20, 26, 256, 256, 3, 1, 0),
+    (2, 16, 32, 64, 64, 3, 1, 0),
+    (1, 24, 48, 128, 128, 3, 1, 0),
+    (1, 8, 16, 64, 64, 3, 1, 1),
+    (1, 32, 64, 64, 128, 3, 2, 0),
     (1, 9, 11, 256, 256, 3, 1, 1),
     (2, 18, 18, 256, 512, 1, 1, 0),
     (1, 18, 22, 256, 256, 3, 2, 0),
