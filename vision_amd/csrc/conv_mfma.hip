@@ -19,7 +19,7 @@
 #include "conv_shapes.h"
 
 #ifndef VAMD_ABLATE
-#define VAMD_ABLATE 0        // 1..4: timing-only experiments on the wide kernel (results are wrong)
+#define VAMD_ABLATE 0        // 1..4 / 5..7: timing-only experiments on the wide / the 128-row kernel (results are wrong)
 #endif
 
 namespace vamd {
@@ -460,13 +460,15 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             a_h0[i] = h0;
             a_w0[i] = w0;
             a_base[i] = UP ? (int)b * gp.Hin * gp.Win * gp.ldx : (((int)b * gp.Hin + h0) * gp.Win + w0) * gp.ldx;
-            uint32_t mask = 0, bit = 1;
-            for (int r = 0; r < gp.kr; ++r) {
-                const bool rok = row_ok && (unsigned)(h0 + r) < (unsigned)gp.He;
-                for (int q = 0; q < gp.ks; ++q, bit <<= 1)
-                    if (rok && (unsigned)(w0 + q) < (unsigned)gp.We) mask |= bit;
-            }
-            a_mask[i] = mask;
+            // tap (r, q) is bit r*ks + q: column validity once, replicated for every valid row
+            // (filters are at most 3 x 3; no loops, no branches)
+            const uint32_t cm = ((unsigned)w0 < (unsigned)gp.We ? 1u : 0u) |
+                                (((gp.ks > 1) & ((unsigned)(w0 + 1) < (unsigned)gp.We)) ? 2u : 0u) |
+                                (((gp.ks > 2) & ((unsigned)(w0 + 2) < (unsigned)gp.We)) ? 4u : 0u);
+            const uint32_t m0 = (row_ok & ((unsigned)h0 < (unsigned)gp.He)) ? cm : 0u;
+            const uint32_t m1 = ((gp.kr > 1) & row_ok & ((unsigned)(h0 + 1) < (unsigned)gp.He)) ? (cm << gp.ks) : 0u;
+            const uint32_t m2 = ((gp.kr > 2) & row_ok & ((unsigned)(h0 + 2) < (unsigned)gp.He)) ? (cm << (2 * gp.ks)) : 0u;
+            a_mask[i] = m0 | m1 | m2;
         }
         f = chunk * PIECE;
         c = f; tr = 0; ts = 0; tap = 0;
@@ -535,11 +537,15 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         // measured: the narrow tile (3 workgroups per CU) runs faster with all loads of the next
         // K-step issued before the first MFMA half, the wide one with the filter rows issued later
         read_frags(buf, 0, a, b);
+#if VAMD_ABLATE != 7
         if constexpr (stage_now) stage_a(buf ^ 1);
         if constexpr (stage_now && BN == 64) stage_b(buf ^ 1);
+#endif
         mma(a, b);
         read_frags(buf, 1, a, b);
+#if VAMD_ABLATE != 7
         if constexpr (stage_now && BN != 64) stage_b(buf ^ 1);
+#endif
         mma(a, b);
     };
 
@@ -666,12 +672,20 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         rt += rstep;
         const bool more = rt < row_tiles;
         if (more) {
+#if VAMD_ABLATE != 5
             setup(rt);
+#else
+            f = chunk * PIECE; c = f; tr = 0; ts = 0; tap = 0; advance();
+#endif
             kstep(buf, std::true_type{});
         } else {
             kstep(buf, std::false_type{});
         }
+#if VAMD_ABLATE != 6
         write_tile(cur);                                  // the staged loads stay in flight meanwhile
+#else
+        if (acc[0][0][0] == 123.456f) write_tile(cur);
+#endif
         if (!more) break;
         init_acc();
         cur = rt;
@@ -791,13 +805,15 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             a_h0[i] = h0;
             a_w0[i] = w0;
             a_base[i] = UP ? (int)b * gp.Hin * gp.Win * gp.ldx : (((int)b * gp.Hin + h0) * gp.Win + w0) * gp.ldx;
-            uint32_t mask = 0, bit = 1;
-            for (int r = 0; r < gp.kr; ++r) {
-                const bool rok = row_ok && (unsigned)(h0 + r) < (unsigned)gp.He;
-                for (int q = 0; q < gp.ks; ++q, bit <<= 1)
-                    if (rok && (unsigned)(w0 + q) < (unsigned)gp.We) mask |= bit;
-            }
-            a_mask[i] = mask;
+            // tap (r, q) is bit r*ks + q: column validity once, replicated for every valid row
+            // (filters are at most 3 x 3; no loops, no branches)
+            const uint32_t cm = ((unsigned)w0 < (unsigned)gp.We ? 1u : 0u) |
+                                (((gp.ks > 1) & ((unsigned)(w0 + 1) < (unsigned)gp.We)) ? 2u : 0u) |
+                                (((gp.ks > 2) & ((unsigned)(w0 + 2) < (unsigned)gp.We)) ? 4u : 0u);
+            const uint32_t m0 = (row_ok & ((unsigned)h0 < (unsigned)gp.He)) ? cm : 0u;
+            const uint32_t m1 = ((gp.kr > 1) & row_ok & ((unsigned)(h0 + 1) < (unsigned)gp.He)) ? (cm << gp.ks) : 0u;
+            const uint32_t m2 = ((gp.kr > 2) & row_ok & ((unsigned)(h0 + 2) < (unsigned)gp.He)) ? (cm << (2 * gp.ks)) : 0u;
+            a_mask[i] = m0 | m1 | m2;
         }
         f = chunk * PIECE;
         c = f; tr = 0; ts = 0; tap = 0;
