@@ -445,7 +445,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         }
     };
     auto setup = [&](int row_tile) {                      // staging state of K-step 0 of a tile
-        const int z = row_tile / m_tiles, mt = row_tile - z * m_tiles;
+        const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
         rx = make_rsrc(x + (int64_t)z * strideA);
         rw = make_rsrc(w + (int64_t)z * strideB);
 #pragma unroll
@@ -574,7 +574,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         }
     };
     auto write_tile = [&](int row_tile) {
-        const int z = row_tile / m_tiles, mt = row_tile - z * m_tiles;
+        const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
         const T* res = reinterpret_cast<const T*>(ep.res);
         const T* res2 = reinterpret_cast<const T*>(ep.res2);
         constexpr int CH = 16 / (int)sizeof(T);           // channels per 16-byte piece of T: 8 (bf16) or 4
@@ -790,7 +790,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         }
     };
     auto setup = [&](int row_tile) {                      // staging state of K-step 0 of a tile
-        const int z = row_tile / m_tiles, mt = row_tile - z * m_tiles;
+        const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
         rx = make_rsrc(x + (int64_t)z * strideA);
         rw = make_rsrc(w + (int64_t)z * strideB);
 #pragma unroll
@@ -910,7 +910,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         }
     };
     auto write_tile = [&](int row_tile) {
-        const int z = row_tile / m_tiles, mt = row_tile - z * m_tiles;
+        const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
         const T* res = reinterpret_cast<const T*>(ep.res);
         const T* res2 = reinterpret_cast<const T*>(ep.res2);
         constexpr int CH = 16 / (int)sizeof(T);           // channels per 16-byte piece of T: 8 (bf16) or 4
@@ -990,7 +990,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
 
     // the same outputs with the channel piece as the outer loop, so that only 2 x CH sums are live
     auto write_tile_stats_lds = [&](int row_tile) {
-        const int z = row_tile / m_tiles, mt = row_tile - z * m_tiles;
+        const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
         const T* res = reinterpret_cast<const T*>(ep.res);
         const T* res2 = reinterpret_cast<const T*>(ep.res2);
         constexpr int CH = 16 / (int)sizeof(T);
