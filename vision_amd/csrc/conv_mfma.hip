@@ -19,7 +19,7 @@
 #include "conv_shapes.h"
 
 #ifndef VAMD_ABLATE
-#define VAMD_ABLATE 0        // 1..4 / 5..7: timing-only experiments on the wide / the 128-row kernel (results are wrong)
+#define VAMD_ABLATE 0        // 1..4 / 5..7 / 8: timing-only experiments on the wide / the 128-row / the weight-gradient kernel (results are wrong)
 #endif
 
 namespace vamd {
@@ -1486,8 +1486,10 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
                 // measured: both halves of the next stage issued before the first MFMA half beat
                 // issuing the second half later
                 read_frags(cur, std::integral_constant<int, 0>{}, ra, rb);
+#if VAMD_ABLATE != 8
                 stage_a(nxt);
                 stage_b(nxt);
+#endif
                 frag_wait(ra, rb, a, b);
                 mma(a, b);
                 read_frags(cur, std::integral_constant<int, 1>{}, ra, rb);
