@@ -4,7 +4,7 @@
  *
  * The reference is pure Python on torch; it has no FFI of its own.  Each entry point below
  * therefore cites the reference *call site* (file:line) whose torch operator(s) it replaces.
- * A maintainer binds these with ctypes (see INTEGRATION.md); `vision_amd/_lib.py` is that binding.
+ * A maintainer binds these with ctypes; `vision_amd/_lib.py` is that binding.
  *
  * Conventions
  *   - Every pointer is a DEVICE pointer owned by the caller.  The library never allocates,
