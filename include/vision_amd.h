@@ -84,6 +84,16 @@ int vamd_conv2d_stats_parts(const vamd_conv_desc* d);
  * Autograd mirror of the call sites listed for vamd_conv2d_fwd. */
 int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, const void* add,
                       void* dx, void* workspace, size_t workspace_bytes, void* stream);
+/* Input gradient of an upsampling descriptor (nearest 2x -> 3x3 conv, models/ddpm.py:29-41) as one
+ * stride-2 convolution over dy with the combined 4x4 filter `w_up4` ([Cin][4][4][Cout], from
+ * vamd_repack_weight_up4): 16 taps per input pixel instead of 36, no pooling pass, no workspace.
+ * vamd_conv2d_dgrad_up4_supported tells whether the MFMA path serves the descriptor this way;
+ * vamd_conv2d_dgrad remains valid for every descriptor. */
+int vamd_conv2d_dgrad_up4_supported(const vamd_conv_desc* d);
+int vamd_conv2d_dgrad_up4(const vamd_conv_desc* d, const void* dy, const void* w_up4, const void* add,
+                          void* dx, void* stream);
+/* fp32 [Cout][Cin][3][3] -> the combined filter above, in `dtype`. */
+int vamd_repack_weight_up4(const float* w_oihw, void* w_up4, int Cout, int Cin, int dtype, void* stream);
 /* Scratch bytes vamd_conv2d_dgrad needs for this descriptor (0 for most; the gradient through the
  * fused upsample is formed at the upsampled resolution first). */
 size_t vamd_conv2d_dgrad_workspace(const vamd_conv_desc* d);

@@ -180,6 +180,20 @@ def test_conv_fwd_dgrad_wgrad(case, dts, algo):
     call("vamd_conv2d_dgrad", C.byref(d), P(dyn), P(wd), P(nhwc(add)), P(dx), P(ws), nbytes, S())
     assert relerr(dx.permute(0, 3, 1, 2), gx64 + add64) < TOL_OUT[dts]
 
+    if up and lib.vamd_conv2d_dgrad_up4_supported(C.byref(d)):
+        # the same gradient as one stride-2 convolution with the combined 4x4 filter
+        w4 = torch.full((Cin, 4, 4, Cout), 7.0, dtype=tdt, device=DEV)
+        call("vamd_repack_weight_up4", P(w64.detach().float().to(DEV).contiguous()), P(w4), Cout, Cin, dt, S())
+        sets = [[2], [1, 2], [0, 1], [0]]
+        g4 = torch.stack([torch.stack([sum(w64.detach()[:, :, r, q] for r in sets[t] for q in sets[u]) for u in range(4)], 0)
+                          for t in range(4)], 0)                     # [4][4][Cout][Cin]
+        assert relerr(w4.permute(1, 2, 3, 0), g4) < (1e-6 if dts == "f32" else 3e-3)
+        dx4 = torch.full((B, H, W, Cin), 7.0, dtype=tdt, device=DEV)
+        call("vamd_conv2d_dgrad_up4", C.byref(d), P(dyn), P(w4), None, P(dx4), S())
+        assert relerr(dx4.permute(0, 3, 1, 2), gx64) < TOL_OUT[dts]
+        call("vamd_conv2d_dgrad_up4", C.byref(d), P(dyn), P(w4), P(nhwc(add)), P(dx4), S())
+        assert relerr(dx4.permute(0, 3, 1, 2), gx64 + add64) < TOL_OUT[dts]
+
     dwk = torch.full((Cout, k, k, Cin), 7.0, dtype=torch.float32, device=DEV)   # must be overwritten
     wbytes = lib.vamd_conv2d_wgrad_workspace(C.byref(d))
     wws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=DEV)

@@ -167,6 +167,26 @@ int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, 
     return conv_dgrad_direct(g, d->dtype, dy, w_t, add, dx, as_stream(stream));
 }
 
+int vamd_conv2d_dgrad_up4_supported(const vamd_conv_desc* d) {
+    ConvGeom g;
+    if (conv_geom(d, &g, "vamd_conv2d_dgrad_up4_supported")) return 0;
+    return (d->algo == kAuto || d->algo == kMfma) && conv_dgrad_up4_mfma_supported(g, d->dtype) ? 1 : 0;
+}
+
+int vamd_conv2d_dgrad_up4(const vamd_conv_desc* d, const void* dy, const void* w4, const void* add, void* dx,
+                          void* stream) {
+    ConvGeom g;
+    int rc = conv_geom(d, &g, "vamd_conv2d_dgrad_up4");
+    if (rc) return rc;
+    VAMD_REQUIRE(dy && w4 && dx, "vamd_conv2d_dgrad_up4: null tensor");
+    VAMD_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)w4 % 16 == 0 && (uintptr_t)dx % 16 == 0,
+                 "vamd_conv2d_dgrad_up4: tensors must be 16-byte aligned");
+    if (!conv_dgrad_up4_mfma_supported(g, d->dtype))
+        return fail(VAMD_EUNSUPPORTED, "vamd_conv2d_dgrad_up4: needs an upsampling 3x3 descriptor the MFMA path covers (Cin=%d Cout=%d up=%d)",
+                    g.Cin, g.Cout, g.up);
+    return conv_dgrad_up4_mfma(g, d->dtype, dy, w4, add, dx, as_stream(stream));
+}
+
 // workspace layout of the thin / direct kernels when the caller wants torch's layout: their own
 // scratch first, then a [Cout][k][k][Cin] fp32 staging copy of the gradient
 static size_t staging_offset(const ConvGeom& g, int dtype, int a) {

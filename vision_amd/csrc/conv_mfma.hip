@@ -464,14 +464,16 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             a_w0[i] = w0;
             a_base[i] = UP ? (int)b * gp.Hin * gp.Win * gp.ldx : (((int)b * gp.Hin + h0) * gp.Win + w0) * gp.ldx;
             // tap (r, q) is bit r*ks + q: column validity once, replicated for every valid row
-            // (filters are at most 3 x 3; no loops, no branches)
+            // (filters are at most 4 x 4; no loops, no branches)
             const uint32_t cm = ((unsigned)w0 < (unsigned)gp.We ? 1u : 0u) |
                                 (((gp.ks > 1) & ((unsigned)(w0 + 1) < (unsigned)gp.We)) ? 2u : 0u) |
-                                (((gp.ks > 2) & ((unsigned)(w0 + 2) < (unsigned)gp.We)) ? 4u : 0u);
+                                (((gp.ks > 2) & ((unsigned)(w0 + 2) < (unsigned)gp.We)) ? 4u : 0u) |
+                                (((gp.ks > 3) & ((unsigned)(w0 + 3) < (unsigned)gp.We)) ? 8u : 0u);
             const uint32_t m0 = (row_ok & ((unsigned)h0 < (unsigned)gp.He)) ? cm : 0u;
             const uint32_t m1 = ((gp.kr > 1) & row_ok & ((unsigned)(h0 + 1) < (unsigned)gp.He)) ? (cm << gp.ks) : 0u;
             const uint32_t m2 = ((gp.kr > 2) & row_ok & ((unsigned)(h0 + 2) < (unsigned)gp.He)) ? (cm << (2 * gp.ks)) : 0u;
-            a_mask[i] = m0 | m1 | m2;
+            const uint32_t m3 = ((gp.kr > 3) & row_ok & ((unsigned)(h0 + 3) < (unsigned)gp.He)) ? (cm << (3 * gp.ks)) : 0u;
+            a_mask[i] = m0 | m1 | m2 | m3;
         }
         f = chunk * PIECE;
         c = f; tr = 0; ts = 0; tap = 0;
@@ -809,14 +811,16 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             a_w0[i] = w0;
             a_base[i] = UP ? (int)b * gp.Hin * gp.Win * gp.ldx : (((int)b * gp.Hin + h0) * gp.Win + w0) * gp.ldx;
             // tap (r, q) is bit r*ks + q: column validity once, replicated for every valid row
-            // (filters are at most 3 x 3; no loops, no branches)
+            // (filters are at most 4 x 4; no loops, no branches)
             const uint32_t cm = ((unsigned)w0 < (unsigned)gp.We ? 1u : 0u) |
                                 (((gp.ks > 1) & ((unsigned)(w0 + 1) < (unsigned)gp.We)) ? 2u : 0u) |
-                                (((gp.ks > 2) & ((unsigned)(w0 + 2) < (unsigned)gp.We)) ? 4u : 0u);
+                                (((gp.ks > 2) & ((unsigned)(w0 + 2) < (unsigned)gp.We)) ? 4u : 0u) |
+                                (((gp.ks > 3) & ((unsigned)(w0 + 3) < (unsigned)gp.We)) ? 8u : 0u);
             const uint32_t m0 = (row_ok & ((unsigned)h0 < (unsigned)gp.He)) ? cm : 0u;
             const uint32_t m1 = ((gp.kr > 1) & row_ok & ((unsigned)(h0 + 1) < (unsigned)gp.He)) ? (cm << gp.ks) : 0u;
             const uint32_t m2 = ((gp.kr > 2) & row_ok & ((unsigned)(h0 + 2) < (unsigned)gp.He)) ? (cm << (2 * gp.ks)) : 0u;
-            a_mask[i] = m0 | m1 | m2;
+            const uint32_t m3 = ((gp.kr > 3) & row_ok & ((unsigned)(h0 + 3) < (unsigned)gp.He)) ? (cm << (3 * gp.ks)) : 0u;
+            a_mask[i] = m0 | m1 | m2 | m3;
         }
         f = chunk * PIECE;
         c = f; tr = 0; ts = 0; tap = 0;
@@ -1854,6 +1858,25 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
         VAMD_LAUNCH_OK("sumpool2x2_add");
     }
     return 0;
+}
+
+// Input gradient of (nearest 2x upsample -> 3x3 conv, pad 1) as ONE stride-2 convolution over dY:
+// input pixel i receives dY rows 2i-1 .. 2i+2 through the filter taps {2}, {1,2}, {0,1}, {0}
+// (the conv taps that read the upsampled copies of row i), so
+//   dx[b, i, j, :] = sum_{t, u < 4} G[t][u] . dY[b, 2i-1+t, 2j-1+u, :],  G[t][u] = sum of w over S(t) x S(u).
+// 16 taps per input pixel instead of 9 taps per upsampled pixel (36 per input pixel) and no pooling pass.
+// `w4` is [Cin][4][4][Cout] in the compute dtype (vamd_repack_weight_up4 builds it).
+bool conv_dgrad_up4_mfma_supported(const ConvGeom& g, int dtype) {
+    if (!g.up || g.k != 3 || g.stride != 1 || g.pad != 1 || nt_classic()) return false;
+    return nt_shape_ok(g.Cout, g.Cin, (int64_t)g.B * g.H * g.W, dtype);
+}
+
+int conv_dgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void* w4, const void* add, void* dx,
+                        hipStream_t st) {
+    Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, g.H, g.W, 4, 2, 1, 0, (int64_t)g.B * g.H * g.W);
+    Epilogue ep{nullptr, nullptr, add, nullptr, 1.0f, 0, nullptr};
+    if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, dy, w4, g.Cin, gp.Ktot, g.Cin, ep, dx, 1, 0, 0, 0, st);
+    return run_nt<float>(gp, dy, w4, g.Cin, gp.Ktot, g.Cin, ep, dx, 1, 0, 0, 0, st);
 }
 
 static bool tn_shape_ok(int Cin, int N, int64_t M, int dtype) {

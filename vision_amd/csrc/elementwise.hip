@@ -431,6 +431,30 @@ repack_weights_kernel(const vamd_repack_item* __restrict__ items, int n) {
     }
 }
 
+// Combined filter of the input gradient of (nearest 2x upsample -> 3x3 conv): along each axis the
+// four dY taps t = 0..3 collect the conv taps {2}, {1,2}, {0,1}, {0}.  w [O][I][3][3] fp32 ->
+// w4 [I][4][4][O] in T (sums formed in fp32, rounded once).
+template <typename T>
+__global__ void repack_weight_up4_kernel(const float* __restrict__ w, T* __restrict__ w4, int O, int I) {
+    const int64_t total = (int64_t)I * 16 * O;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % O);
+        int64_t rest = idx / O;
+        const int u = (int)(rest % 4); rest /= 4;
+        const int t = (int)(rest % 4);
+        const int i = (int)(rest / 4);
+        // taps of S(t): t=0 -> {2}, 1 -> {1,2}, 2 -> {0,1}, 3 -> {0}
+        const int r_lo = t == 0 ? 2 : (t == 1 ? 1 : 0), r_hi = t <= 1 ? 2 : (t == 2 ? 1 : 0);
+        const int s_lo = u == 0 ? 2 : (u == 1 ? 1 : 0), s_hi = u <= 1 ? 2 : (u == 2 ? 1 : 0);
+        const float* src = w + ((int64_t)o * I + i) * 9;
+        float sum = 0.f;
+        for (int r = r_lo; r <= r_hi; ++r)
+            for (int q = s_lo; q <= s_hi; ++q) sum += src[r * 3 + q];
+        w4[idx] = from_f<T>(sum);
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwk, float* __restrict__ dw, int O,
                                     int I, int k) {
     const int64_t total = (int64_t)O * I * k * k;
@@ -690,6 +714,17 @@ int vamd_repack_weights(const vamd_repack_item* items_dev, int n, long long tota
                            items_dev, n);
     });
     VAMD_LAUNCH_OK("vamd_repack_weights");
+    return 0;
+}
+
+int vamd_repack_weight_up4(const float* w, void* w4, int Cout, int Cin, int dtype, void* stream) {
+    VAMD_REQUIRE(w && w4 && Cout > 0 && Cin > 0, "vamd_repack_weight_up4: bad argument");
+    const int64_t total = (int64_t)Cin * 16 * Cout;
+    VAMD_DISPATCH(dtype, "vamd_repack_weight_up4", {
+        hipLaunchKernelGGL(repack_weight_up4_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), w,
+                           (T*)w4, Cout, Cin);
+    });
+    VAMD_LAUNCH_OK("vamd_repack_weight_up4");
     return 0;
 }
 

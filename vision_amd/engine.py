@@ -44,11 +44,17 @@ class _Conv:
         self.gw, self.gb = eng.grad(name + ".weight"), eng.grad(name + ".bias")
         self.wf = torch.empty((cout, k, k, cin), dtype=eng.dtype, device=eng.device)
         self.wd = torch.empty((cin, k, k, cout), dtype=eng.dtype, device=eng.device)
+        # upsampling convs: combined 4x4 stride-2 filter of the input gradient (filled by repack_up4)
+        self.wd4 = torch.empty((cin, 4, 4, cout), dtype=eng.dtype, device=eng.device) if up and k == 3 else None
         self._descs: Dict[tuple, ConvDesc] = {}
 
     def repack(self):
         call("vamd_repack_weight", _ptr(self.w), _ptr(self.wf), _ptr(self.wd), self.cout, self.cin,
              self.k, self.eng.dt, _stream())
+
+    def repack_up4(self):
+        if self.wd4 is not None:
+            call("vamd_repack_weight_up4", _ptr(self.w), _ptr(self.wd4), self.cout, self.cin, self.eng.dt, _stream())
 
     def desc(self, B, H, W) -> ConvDesc:
         key = (B, H, W)
@@ -111,6 +117,12 @@ class _Conv:
         B, H, W, _ = in_shape
         d = self.desc(B, H, W)
         dx = torch.empty(in_shape, dtype=self.eng.dtype, device=dy.device)
+        if self.wd4 is not None and lib.vamd_conv2d_dgrad_up4_supported(C.byref(d)):
+            ev = self._timed(1, B, H, W)
+            call("vamd_conv2d_dgrad_up4", C.byref(d), _ptr(dy), _ptr(self.wd4), _ptr(add), _ptr(dx), _stream())
+            if ev is not None:
+                ev.record()
+            return dx
         nbytes = lib.vamd_conv2d_dgrad_workspace(C.byref(d))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device) if nbytes else None
         ev = self._timed(1, B, H, W)
@@ -530,6 +542,8 @@ class Engine:
                 self._repack_table = (raw, len(convs), blocks)
             raw, n, blocks = self._repack_table
             call("vamd_repack_weights", _ptr(raw), n, blocks, self.dt, _stream())
+            for c in self.all_convs():
+                c.repack_up4()
             self._versions = vers
             self.dirty = False
 
