@@ -198,7 +198,9 @@ size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_wgrad_workspace")) return 0;
     const int a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), "", g);
-    if (a == kMfma) return conv_wgrad_mfma_workspace(g, d->dtype);
+    if (a == kMfma)
+        return conv_wgrad_up4_mfma_supported(g, d->dtype) ? conv_wgrad_up4_mfma_workspace(g, d->dtype)
+                                                          : conv_wgrad_mfma_workspace(g, d->dtype);
     return staging_offset(g, d->dtype, a) + (size_t)g.Cout * g.k * g.k * g.Cin * sizeof(float);
 }
 
@@ -212,8 +214,11 @@ static int conv2d_wgrad_impl(const char* who, const vamd_conv_desc* d, const voi
                  "%s: tensors must be 16-byte aligned", who);
     const int a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), who, g);
     if (a < 0) return a;
-    if (a == kMfma)
+    if (a == kMfma) {
+        if (conv_wgrad_up4_mfma_supported(g, d->dtype))
+            return conv_wgrad_up4_mfma(g, d->dtype, dy, x, dw, dbias, oihw, workspace, workspace_bytes, as_stream(stream));
         return conv_wgrad_mfma(g, d->dtype, dy, x, dw, dbias, oihw, workspace, workspace_bytes, as_stream(stream));
+    }
     if (dbias) {                     // the other kernels do not produce it: one extra pass over dy
         rc = column_sums(d->dtype, dy, g.M, g.Cout, dbias, as_stream(stream));
         if (rc) return rc;

@@ -1250,7 +1250,7 @@ __global__ void __launch_bounds__(256, 2)
 conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x, int N, int lda, int ldc,
                     float* __restrict__ dw, int n_tiles, int f_tiles, int steps_per_slice,
                     int64_t strideA, int64_t strideB, int64_t strideC, int out_mode, void* yout,
-                    float alpha, float* __restrict__ dbias) {
+                    float alpha, float* __restrict__ dbias, int bias_mode) {
     constexpr int PIECE = ElemTraits<T>::PIECE;
     constexpr bool BF16 = sizeof(T) == 2;
     constexpr int KP = BF16 ? 64 : 32;                    // pixels per K-step
@@ -1359,7 +1359,10 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // bias gradient: the workgroups of the first filter-column tile also multiply dY^T by a column
     // of ones (every column of the product is the per-channel pixel sum)
-    const bool do_bias = dbias != nullptr && ft == 0 && wn == 0;      // wave-uniform
+    // bias_mode 2: pixel sums of the gathered operand's columns instead (ones^T x B), by the waves of
+    // the first dY-column tile: used when the roles of the operands are swapped
+    const bool do_bias = dbias != nullptr && bias_mode == 1 && ft == 0 && wn == 0;      // wave-uniform
+    const bool do_bsum = dbias != nullptr && bias_mode == 2 && nt == 0 && wm == 0;
     f32x4_t accb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -1435,6 +1438,13 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
 #pragma unroll
             for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
         }
+        if (do_bsum) {
+            bf16x8_t ones;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b[j], accb[j], 0, 0, 0);
+        }
     };
     // fp32: 16x16x4, lane l holds A[i = l&15][k = l>>4]; tile rows are pixels, so element (k, i)
     // sits at row k, column i: plain 4-byte reads, 16 consecutive lanes contiguous.
@@ -1460,6 +1470,10 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
             if (do_bias) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], 1.0f, accb[i], 0, 0, 0);
+            }
+            if (do_bsum) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, b[j], accb[j], 0, 0, 0);
             }
         }
     };
@@ -1526,6 +1540,14 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
                 const int nrow = n0 + wm * 64 + i * 16 + fq * 4 + r;
                 if (nrow < N) pb[nrow] = accb[i][r];
             }
+    }
+    if (do_bsum && fq == 0) {                             // every row of ones^T x B is the column sum
+        float* pb = dbias + (int64_t)slice * gp.Ktot;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int fcol = f0 + wn * (16 * NJ) + j * 16 + fr;
+            if (fcol < gp.Ktot) pb[fcol] = accb[j][0];
+        }
     }
     if (out_mode == 0) {
         float* part = dw + (int64_t)slice * N * ldc;
@@ -1987,7 +2009,7 @@ wgrad_reduce_kernel(const float* __restrict__ parts, const float* __restrict__ b
 template <typename T, int AN, int BF>
 static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
                            int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, float* dbias,
-                           hipStream_t st) {
+                           int bias_mode, hipStream_t st) {
     constexpr int KP = sizeof(T) == 2 ? 64 : 32;
     constexpr int LDS = 2 * KP * (AN + BF) * (int)sizeof(T);
     static bool configured = false;
@@ -2003,7 +2025,7 @@ static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int
     dim3 grid(n_tiles * f_tiles * slices, 1, batch);
     TimedLaunch timed(TIMED_TN, 2.0 * gp.M * N * gp.Ktot * batch, st);
     hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
-                       f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias);
+                       f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode);
     VAMD_LAUNCH_OK("conv_tn_mfma");
     return 0;
 }
@@ -2011,10 +2033,10 @@ static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int
 template <typename T>
 static int launch_tn(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
                      int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, float* dbias,
-                     hipStream_t st) {
+                     int bias_mode, hipStream_t st) {
     if (out_mode == 0 && tn_narrow(N, gp.Ktot))
-        return launch_tn_shape<T, 64, 192>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, st);
-    return launch_tn_shape<T, 128, 128>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, st);
+        return launch_tn_shape<T, 64, 192>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode, st);
+    return launch_tn_shape<T, 128, 128>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode, st);
 }
 
 size_t conv_wgrad_mfma_workspace(const ConvGeom& g, int dtype) {
@@ -2032,9 +2054,9 @@ int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x,
     float* bias_parts = dbias ? parts + (size_t)slices * g.Cout * gp.Ktot : nullptr;
     int rc;
     if (dtype == VAMD_BF16)
-        rc = launch_tn<bf16_t>(gp, (const bf16_t*)dy, (const bf16_t*)x, g.Cout, g.Cout, gp.Ktot, parts, 1, 0, 0, 0, 0, nullptr, 1.f, bias_parts, st);
+        rc = launch_tn<bf16_t>(gp, (const bf16_t*)dy, (const bf16_t*)x, g.Cout, g.Cout, gp.Ktot, parts, 1, 0, 0, 0, 0, nullptr, 1.f, bias_parts, 1, st);
     else
-        rc = launch_tn<float>(gp, (const float*)dy, (const float*)x, g.Cout, g.Cout, gp.Ktot, parts, 1, 0, 0, 0, 0, nullptr, 1.f, bias_parts, st);
+        rc = launch_tn<float>(gp, (const float*)dy, (const float*)x, g.Cout, g.Cout, gp.Ktot, parts, 1, 0, 0, 0, 0, nullptr, 1.f, bias_parts, 1, st);
     if (rc) return rc;
     const int64_t total4 = (int64_t)g.Cout * gp.Ktot / 4;
     const unsigned bias_blocks = dbias ? (unsigned)((g.Cout + 7) / 8) : 0u;
@@ -2045,6 +2067,100 @@ int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x,
         hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total4 + 63) / 64) + bias_blocks), dim3(256), 0, st, parts,
                            bias_parts, slices, g.Cout, gp.Ktot, g.Cin, g.k, oihw, dw, dbias);
     VAMD_LAUNCH_OK("wgrad_reduce");
+    return 0;
+}
+
+// Weight gradient of (nearest 2x upsample -> 3x3 conv): the gradient of the combined 4x4 stride-2
+// filter G of the input-gradient form,  dG[c][t][u][o] = sum over input pixels of x[b,i,j,c] *
+// dY[b, 2i-1+t, 2j-1+u, o]  (the TN kernel with x as the plain operand and dY gathered 4x4 / stride 2:
+// 16 taps per input pixel instead of 36), folded back by  dW[o][c][r][s] = sum of dG over the taps
+// t, u whose sets {2}, {1,2}, {0,1}, {0} contain r, s.  The bias gradient is the pixel sum of the
+// gathered dY columns of the four central taps, which cover every dY pixel exactly once.
+static int up4_slices(const ConvGeom& g, int dtype) {
+    const int F = 16 * g.Cout, KP = dtype == VAMD_BF16 ? 64 : 32;
+    const bool narrow = tn_narrow(g.Cin, F);
+    const int AN = narrow ? 64 : 128, BF = narrow ? 192 : 128;
+    int slices, steps_per;
+    tn_split(((g.Cin + AN - 1) / AN) * ((F + BF - 1) / BF), (int)(((int64_t)g.B * g.H * g.W + KP - 1) / KP), &slices, &steps_per);
+    return slices;
+}
+
+bool conv_wgrad_up4_mfma_supported(const ConvGeom& g, int dtype) {
+    static const int on = [] { const char* e = getenv("VAMD_WGRAD_UP4"); return e ? atoi(e) : 1; }();
+    if (!on || !g.up || g.k != 3 || g.stride != 1 || g.pad != 1 || g.Cout % 4) return false;
+    return tn_shape_ok(g.Cout, g.Cin, (int64_t)g.B * g.H * g.W, dtype);
+}
+
+size_t conv_wgrad_up4_mfma_workspace(const ConvGeom& g, int dtype) {
+    const size_t dg = (size_t)g.Cin * 16 * g.Cout;
+    return ((size_t)up4_slices(g, dtype) * (dg + 16 * g.Cout) + dg) * sizeof(float);
+}
+
+// dG [Cin][4][4][Cout] (already summed over the slices) -> dW, and the bias partials -> dbias
+__global__ void __launch_bounds__(256)
+wgrad_up4_fold_kernel(const float* __restrict__ dg, const float* __restrict__ bias_parts, int slices, int Cin, int Cout,
+                      int oihw, float* __restrict__ dw, float* __restrict__ dbias) {
+    const int64_t total = (int64_t)Cin * Cout;
+    const int64_t idx = blockIdx.x * 256ll + threadIdx.x;
+    if (idx < total) {
+        const int o = (int)(idx % Cout), c = (int)(idx / Cout);     // consecutive lanes: consecutive dG columns
+        float g4[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g4[t][u] = dg[(((int64_t)c * 4 + t) * 4 + u) * Cout + o];
+        // conv tap r collects dY taps: r = 0 <- {2, 3}, r = 1 <- {1, 2}, r = 2 <- {0, 1}
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int t0 = 2 - r, u0 = 2 - q;
+                const float v = (g4[t0][u0] + g4[t0][u0 + 1]) + (g4[t0 + 1][u0] + g4[t0 + 1][u0 + 1]);
+                if (oihw) dw[(((int64_t)o * Cin + c) * 3 + r) * 3 + q] = v;
+                else dw[(((int64_t)o * 3 + r) * 3 + q) * Cin + c] = v;
+            }
+    }
+    if (dbias && blockIdx.x == 0) {
+        for (int o = threadIdx.x; o < Cout; o += 256) {
+            float sum = 0.f;
+            for (int sl = 0; sl < slices; ++sl) {
+                const float* bp = bias_parts + (int64_t)sl * 16 * Cout;
+                sum += (bp[(1 * 4 + 1) * Cout + o] + bp[(1 * 4 + 2) * Cout + o]) + (bp[(2 * 4 + 1) * Cout + o] + bp[(2 * 4 + 2) * Cout + o]);
+            }
+            dbias[o] = sum;
+        }
+    }
+}
+
+int conv_wgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
+                        int oihw, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (!workspace || workspace_bytes < conv_wgrad_up4_mfma_workspace(g, dtype))
+        return fail(VAMD_EINVAL, "conv_wgrad_up4_mfma: needs %zu workspace bytes", conv_wgrad_up4_mfma_workspace(g, dtype));
+    const int64_t M = (int64_t)g.B * g.H * g.W;
+    Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, g.H, g.W, 4, 2, 1, 0, M);
+    const int F = gp.Ktot;                                 // 16 * Cout
+    const int slices = up4_slices(g, dtype);
+    const size_t dgn = (size_t)g.Cin * F;
+    float* parts = reinterpret_cast<float*>(workspace);
+    float* bias_parts = parts + (size_t)slices * dgn;      // [slices][16 * Cout]
+    float* dg = bias_parts + (size_t)slices * F;
+    int rc;
+    if (dtype == VAMD_BF16)
+        rc = launch_tn<bf16_t>(gp, (const bf16_t*)x, (const bf16_t*)dy, g.Cin, g.Cin, F, parts, 1, 0, 0, 0, 0, nullptr, 1.f, dbias ? bias_parts : nullptr, 2, st);
+    else
+        rc = launch_tn<float>(gp, (const float*)x, (const float*)dy, g.Cin, g.Cin, F, parts, 1, 0, 0, 0, 0, nullptr, 1.f, dbias ? bias_parts : nullptr, 2, st);
+    if (rc) return rc;
+    const int64_t total4 = (int64_t)dgn / 4;
+    if (slices >= 32)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((unsigned)((total4 + 7) / 8)), dim3(256), 0, st, parts, nullptr, slices,
+                           g.Cin, F, g.Cout, 1, 0, dg, nullptr);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, parts, nullptr, slices,
+                           g.Cin, F, g.Cout, 1, 0, dg, nullptr);
+    VAMD_LAUNCH_OK("wgrad_reduce");
+    hipLaunchKernelGGL(wgrad_up4_fold_kernel, dim3((unsigned)(((int64_t)g.Cin * g.Cout + 255) / 256)), dim3(256), 0, st, dg,
+                       bias_parts, slices, g.Cin, g.Cout, oihw, dw, dbias);
+    VAMD_LAUNCH_OK("wgrad_up4_fold");
     return 0;
 }
 
@@ -2090,9 +2206,9 @@ int bmm_tn_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N,
     gp.Ktot = N;      // valid output columns
     if (dtype == VAMD_BF16)
         return launch_tn<bf16_t>(gp, (const bf16_t*)A, (const bf16_t*)Bm, M, lda, ldc, nullptr, batch, (int64_t)K * lda,
-                                 (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, nullptr, st);
+                                 (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, nullptr, 0, st);
     return launch_tn<float>(gp, (const float*)A, (const float*)Bm, M, lda, ldc, nullptr, batch, (int64_t)K * lda,
-                            (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, nullptr, st);
+                            (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, nullptr, 0, st);
 }
 
 }  // namespace vamd

@@ -57,6 +57,10 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
 bool conv_dgrad_up4_mfma_supported(const ConvGeom& g, int dtype);
 int conv_dgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void* w4, const void* add, void* dx,
                         hipStream_t st);
+bool conv_wgrad_up4_mfma_supported(const ConvGeom& g, int dtype);
+size_t conv_wgrad_up4_mfma_workspace(const ConvGeom& g, int dtype);
+int conv_wgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
+                        int oihw, void* workspace, size_t workspace_bytes, hipStream_t st);
 bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype);
 size_t conv_wgrad_mfma_workspace(const ConvGeom& g, int dtype);
 int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
