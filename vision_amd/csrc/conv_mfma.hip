@@ -75,6 +75,18 @@ struct Epilogue {
     float* stats;          // [row tiles][N][2]: per row tile, column sums of the stored y and y*y (or NULL)
 };
 
+// Up to four convolutions of one layer in one launch (the output-parity classes of a stride-2 input
+// gradient): the grid is cut into per-class block ranges, a workgroup takes the gather, the tile
+// count, the filter offset and the statistics offset of its class and then runs as usual.
+struct ClassSet {
+    int ncls;                  // <= 1: a plain launch, the kernel's own arguments apply
+    int first_block[5];        // class c owns blocks [first_block[c], first_block[c+1])
+    int m_tiles[4];
+    int64_t w_off[4];          // elements added to the filter pointer
+    int64_t stats_off[4];      // floats added to the statistics pointer
+    Gather g[4];
+};
+
 // Branch-free pointer select: keeps the staging code of a K-step in one basic block, so that the
 // scheduler may place it between MFMAs.
 template <typename T> __device__ __forceinline__ const T* pick_ptr(bool ok, const T* a, const T* b) {
@@ -395,7 +407,7 @@ template <typename T, int BN, bool UP, bool STATS>
 __global__ void __launch_bounds__(256, BN == 64 ? 3 : 2)
 conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
                      Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, int row_tiles,
-                     int64_t strideA, int64_t strideB, int64_t strideC) {
+                     int64_t strideA, int64_t strideB, int64_t strideC, ClassSet cs) {
     constexpr int PIECE = ElemTraits<T>::PIECE;          // elements per 16-byte piece
     constexpr int KSTEP = kRowBytes / sizeof(T);          // reduction elements per K-step
     constexpr int A_BYTES = kBM * kRowBytes;
@@ -410,9 +422,20 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int blk = blockIdx.x, nblk = gridDim.x;
+    if (cs.ncls > 1) {                                     // this workgroup's class (uniform)
+        const int c = (blk >= cs.first_block[1]) + (blk >= cs.first_block[2]) + (blk >= cs.first_block[3]);
+        gp = cs.g[c];
+        m_tiles = cs.m_tiles[c];
+        row_tiles = m_tiles;
+        w += cs.w_off[c];
+        if (ep.stats) ep.stats += cs.stats_off[c];
+        nblk = cs.first_block[c + 1] - cs.first_block[c];
+        blk -= cs.first_block[c];
+    }
+    const int bid = xcd_remap(blk, nblk);
     const int nt = bid % n_tiles;                          // this workgroup's column tile, fixed
-    const int rstep = gridDim.x / n_tiles;                 // row tiles advance by this
+    const int rstep = nblk / n_tiles;                      // row tiles advance by this
     int rt = bid / n_tiles;                                // row tile = (batch z, m tile)
     const int n0 = nt * BN;
 
@@ -739,7 +762,7 @@ template <typename T, int BN, bool UP, bool STATS>
 __global__ void __launch_bounds__(512, 1)
 conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
                      Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, int row_tiles,
-                     int64_t strideA, int64_t strideB, int64_t strideC) {
+                     int64_t strideA, int64_t strideB, int64_t strideC, ClassSet cs) {
     constexpr int PIECE = ElemTraits<T>::PIECE;          // elements per 16-byte piece
     constexpr int KSTEP = kRowBytes / sizeof(T);          // reduction elements per K-step
     constexpr int BM = 256;
@@ -757,9 +780,20 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int blk = blockIdx.x, nblk = gridDim.x;
+    if (cs.ncls > 1) {                                     // this workgroup's class (uniform)
+        const int c = (blk >= cs.first_block[1]) + (blk >= cs.first_block[2]) + (blk >= cs.first_block[3]);
+        gp = cs.g[c];
+        m_tiles = cs.m_tiles[c];
+        row_tiles = m_tiles;
+        w += cs.w_off[c];
+        if (ep.stats) ep.stats += cs.stats_off[c];
+        nblk = cs.first_block[c + 1] - cs.first_block[c];
+        blk -= cs.first_block[c];
+    }
+    const int bid = xcd_remap(blk, nblk);
     const int nt = bid % n_tiles;                          // this workgroup's column tile, fixed
-    const int rstep = gridDim.x / n_tiles;                 // row tiles advance by this
+    const int rstep = nblk / n_tiles;                      // row tiles advance by this
     int rt = bid / n_tiles;                                // row tile = (batch z, m tile)
     const int n0 = nt * BN;
 
@@ -1636,8 +1670,43 @@ static bool nt_wide(int BN, int64_t M, int batch, int n_tiles) {
 
 template <typename T, int BN, bool UP>
 static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
-                     void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
+                     void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st,
+                     const ClassSet* classes = nullptr) {
     constexpr int LDS_PIPE = 2 * (kBM * kRowBytes + BN * kRowBytes);
+    ClassSet cs;
+    cs.ncls = 0;
+    // a class set: block ranges in proportion to the classes' work, tile counts for the tile height used
+    auto plan_classes = [&](int bm, int slots_per_column, double* flops) {
+        cs = *classes;
+        // a tile costs its K-steps plus a fixed part (set-up, epilogue) worth about `ovh` reduction elements;
+        // every class gets the fewest workgroups per column tile that finish it within a common time budget,
+        // the smallest budget for which all of them fit on the chip at once
+        static const int ovh = [] { const char* e = getenv("VAMD_CLASS_OVH"); return e ? atoi(e) : 256; }();
+        int64_t cost[4], hi = 0;
+        for (int c = 0; c < cs.ncls; ++c) {
+            cs.m_tiles[c] = (cs.g[c].M + bm - 1) / bm;
+            cost[c] = cs.g[c].Ktot + ovh;
+            if (cost[c] * cs.m_tiles[c] > hi) hi = cost[c] * cs.m_tiles[c];
+            *flops += 2.0 * cs.g[c].M * N * cs.g[c].Ktot;
+        }
+        auto groups_for = [&](int c, int64_t budget) {
+            int64_t per = budget / cost[c];
+            if (per < 1) per = 1;
+            return (int)((cs.m_tiles[c] + per - 1) / per);
+        };
+        int64_t lo = 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            int need = 0;
+            for (int c = 0; c < cs.ncls; ++c) need += groups_for(c, mid);
+            if (need <= slots_per_column) hi = mid; else lo = mid + 1;
+        }
+        const int n_tiles_ = (N + BN - 1) / BN;
+        cs.first_block[0] = 0;
+        for (int c = 0; c < 4; ++c)
+            cs.first_block[c + 1] = cs.first_block[c] + (c < cs.ncls ? groups_for(c, lo) * n_tiles_ : 0);
+        return cs.first_block[4];
+    };
     constexpr int LDS_EPI = kBM * (BN + 4) * 4;
     constexpr int LDS = LDS_PIPE > LDS_EPI ? LDS_PIPE : LDS_EPI;
     const int m_tiles = (gp.M + kBM - 1) / kBM, n_tiles = (N + BN - 1) / BN;
@@ -1666,14 +1735,16 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
             }
             const int mw_tiles = (gp.M + 255) / 256;
             const int row_tiles = mw_tiles * batch;
-            const int groups = ntp_row_groups(row_tiles, n_tiles, 1);
-            TimedLaunch timed(TIMED_NT, 2.0 * gp.M * N * gp.Ktot * batch, st);
+            int blocks = ntp_row_groups(row_tiles, n_tiles, 1) * n_tiles;
+            double flops = classes ? 0.0 : 2.0 * gp.M * N * gp.Ktot * batch;
+            if (classes) blocks = plan_classes(256, 256 / n_tiles > 0 ? 256 / n_tiles : 1, &flops);
+            TimedLaunch timed(TIMED_NT, flops, st);
             if (ep.stats)
-                hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, true>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp,
-                                   x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
+                hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, true>), dim3(blocks), dim3(512), LDS_W, st, gp,
+                                   x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
             else
-                hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, false>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp,
-                                   x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
+                hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, false>), dim3(blocks), dim3(512), LDS_W, st, gp,
+                                   x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
             VAMD_LAUNCH_OK("conv_ntw_mfma");
             return 0;
         }
@@ -1686,14 +1757,19 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
         configured_p = true;
     }
     const int row_tiles = m_tiles * batch;
-    const int groups = ntp_row_groups(row_tiles, n_tiles, ntp_per_cu(BN));
-    TimedLaunch timed(TIMED_NT, 2.0 * gp.M * N * gp.Ktot * batch, st);
+    int blocks = ntp_row_groups(row_tiles, n_tiles, ntp_per_cu(BN)) * n_tiles;
+    double flops = classes ? 0.0 : 2.0 * gp.M * N * gp.Ktot * batch;
+    if (classes) {
+        const int per_column = 256 * ntp_per_cu(BN) / n_tiles;
+        blocks = plan_classes(kBM, per_column > 0 ? per_column : 1, &flops);
+    }
+    TimedLaunch timed(TIMED_NT, flops, st);
     if (ep.stats)
-        hipLaunchKernelGGL((conv_ntp_mfma_kernel<T, BN, UP, true>), dim3(groups * n_tiles), dim3(256), LDS_PIPE, st, gp, x,
-                           w, N, ldw, ldc, ep, y, m_tiles, n_tiles, row_tiles, sA, sB, sC);
+        hipLaunchKernelGGL((conv_ntp_mfma_kernel<T, BN, UP, true>), dim3(blocks), dim3(256), LDS_PIPE, st, gp, x,
+                           w, N, ldw, ldc, ep, y, m_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
     else
-        hipLaunchKernelGGL((conv_ntp_mfma_kernel<T, BN, UP, false>), dim3(groups * n_tiles), dim3(256), LDS_PIPE, st, gp, x,
-                           w, N, ldw, ldc, ep, y, m_tiles, n_tiles, row_tiles, sA, sB, sC);
+        hipLaunchKernelGGL((conv_ntp_mfma_kernel<T, BN, UP, false>), dim3(blocks), dim3(256), LDS_PIPE, st, gp, x,
+                           w, N, ldw, ldc, ep, y, m_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
     VAMD_LAUNCH_OK("conv_ntp_mfma");
     return 0;
 }
@@ -1725,19 +1801,26 @@ static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ld
     const int row_tiles = mw_tiles * batch;
     const int groups = ntp_row_groups(row_tiles, n_tiles, 1);
     TimedLaunch timed(TIMED_NT, 2.0 * gp.M * N * gp.Ktot * batch, st);
+    ClassSet cs;
+    cs.ncls = 0;
     if (ep.stats)
         hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, 256, UP, true>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp, x, w, N,
-                           ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
+                           ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
     else
         hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, 256, UP, false>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp, x, w, N,
-                           ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC);
+                           ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
     VAMD_LAUNCH_OK("conv_ntw_mfma");
     return 0;
 }
 
 template <typename T>
 static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep,
-                  void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
+                  void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st,
+                  const ClassSet* classes = nullptr) {
+    if (classes) {                                        // class sets: stride-1 gathers without upsampling
+        if (N <= 64) return launch_nt<T, 64, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
+        return launch_nt<T, 128, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
+    }
     if constexpr (sizeof(T) == 2) {
         if (nt_wide256(N, gp.M, batch, sizeof(T), gp.Ktot, gp.shift != 0)) {
             if (gp.shift) return launch_ntw256<T, true>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
@@ -1827,6 +1910,11 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
     //             by inserted zeros.
     if (g.stride == 2) {
         const int padT = g.k - 1 - g.pad;
+        static const int merged = [] { const char* e = getenv("VAMD_DGRAD_CLASSES"); return e ? atoi(e) : 1; }();
+        ClassSet set;
+        set.ncls = 0;
+        const int ldw = g.k * g.k * g.Cout;
+        Epilogue ep{nullptr, nullptr, add, nullptr, 1.0f, 0, nullptr};
         for (int ph = 0; ph < 2; ++ph)
             for (int pw = 0; pw < 2; ++pw) {
                 const int Hc = (g.H - ph + 1) / 2, Wc = (g.W - pw + 1) / 2;     // pixels of this class
@@ -1847,12 +1935,25 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
                 gp.Ktot = kr * kc * g.Cout;
                 gp.wr0 = r0; gp.ws0 = s0; gp.wstep = 2; gp.wk = g.k;
                 gp.oH = g.H; gp.oW = g.W; gp.ostep = 2; gp.oph = ph; gp.opw = pw;
-                Epilogue ep{nullptr, nullptr, add, nullptr, 1.0f, 0, nullptr};
-                const int ldw = g.k * g.k * g.Cout;
+                if (merged && !nt_classic()) {            // one launch for all classes
+                    set.g[set.ncls] = gp;
+                    set.w_off[set.ncls] = 0;
+                    set.stats_off[set.ncls] = 0;
+                    ++set.ncls;
+                    continue;
+                }
                 int rc = dtype == VAMD_BF16 ? run_nt<bf16_t>(gp, dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st)
                                             : run_nt<float>(gp, dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st);
                 if (rc) return rc;
             }
+        if (set.ncls == 1) {
+            return dtype == VAMD_BF16 ? run_nt<bf16_t>(set.g[0], dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st)
+                                      : run_nt<float>(set.g[0], dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st);
+        }
+        if (set.ncls > 1) {
+            return dtype == VAMD_BF16 ? run_nt<bf16_t>(set.g[0], dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st, &set)
+                                      : run_nt<float>(set.g[0], dy, wt, g.Cin, ldw, g.Cin, ep, dx, 1, 0, 0, 0, st, &set);
+        }
         return 0;
     }
     const int rowsH = g.up ? g.He : g.H, rowsW = g.up ? g.We : g.W;   // extents the GEMM rows enumerate
