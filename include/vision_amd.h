@@ -84,6 +84,17 @@ int vamd_conv2d_stats_parts(const vamd_conv_desc* d);
  * Autograd mirror of the call sites listed for vamd_conv2d_fwd. */
 int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, const void* add,
                       void* dx, void* workspace, size_t workspace_bytes, void* stream);
+/* Forward of an upsampling descriptor (nearest 2x -> 3x3 conv, models/ddpm.py:29-41) as four 2x2
+ * convolutions over the stored input, one per output parity class, in one launch: 16 taps per stored
+ * pixel instead of 36.  `w_up4` is [4][Cout][2][2][Cin] from vamd_repack_weight_up4_fwd; epilogue
+ * operands as in vamd_conv2d_fwd; `stats` (may be NULL) as in vamd_conv2d_fwd_stats with
+ * vamd_conv2d_fwd_up4_stats_parts(d) leading rows. */
+int vamd_conv2d_fwd_up4_supported(const vamd_conv_desc* d);
+int vamd_conv2d_fwd_up4_stats_parts(const vamd_conv_desc* d);
+int vamd_conv2d_fwd_up4(const vamd_conv_desc* d, const void* x, const void* w_up4, const float* bias,
+                        const float* temb, const void* residual, const void* residual2, void* y, float* stats,
+                        void* stream);
+int vamd_repack_weight_up4_fwd(const float* w_oihw, void* w_up4, int Cout, int Cin, int dtype, void* stream);
 /* Input gradient of an upsampling descriptor (nearest 2x -> 3x3 conv, models/ddpm.py:29-41) as one
  * stride-2 convolution over dy with the combined 4x4 filter `w_up4` ([Cin][4][4][Cout], from
  * vamd_repack_weight_up4): 16 taps per input pixel instead of 36, no pooling pass, no workspace.

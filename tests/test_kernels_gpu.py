@@ -168,6 +168,21 @@ def test_conv_fwd_dgrad_wgrad(case, dts, algo):
         assert relerr(folded.sum(0), want) < 1e-5
         assert relerr(folded[0], part[0::nout].sum(0)) < 1e-6
 
+    if up and lib.vamd_conv2d_fwd_up4_supported(C.byref(d)):
+        # the same forward as four 2x2 class convolutions over the stored input
+        wu = torch.full((4, Cout, 2, 2, Cin), 7.0, dtype=tdt, device=DEV)
+        call("vamd_repack_weight_up4_fwd", P(w64.detach().float().to(DEV).contiguous()), P(wu), Cout, Cin, dt, S())
+        y4 = torch.full((B, Ho, Wo, Cout), 7.0, dtype=tdt, device=DEV)
+        call("vamd_conv2d_fwd_up4", C.byref(d), P(xn), P(wu), None, None, None, None, P(y4), None, S())
+        assert relerr(y4.permute(0, 3, 1, 2), y64.detach()) < TOL_OUT[dts]
+        np4 = lib.vamd_conv2d_fwd_up4_stats_parts(C.byref(d))
+        part4 = torch.full((np4, Cout, 2), 7.0, dtype=torch.float32, device=DEV)
+        call("vamd_conv2d_fwd_up4", C.byref(d), P(xn), P(wu), P(bias.to(DEV)), P(temb.to(DEV)), P(nhwc(res)), P(nhwc(res2)),
+             P(y4), P(part4), S())
+        assert relerr(y4.permute(0, 3, 1, 2), full64.detach()) < TOL_OUT[dts]
+        yd4 = y4.double().cpu().reshape(-1, Cout)
+        assert relerr(part4.sum(0), torch.stack([yd4.sum(0), (yd4 * yd4).sum(0)], 1)) < 1e-5
+
     dy, dy64 = rnd((B, Cout, Ho, Wo), tdt, gen)
     gx64, gw64 = torch.autograd.grad(y64, [x64, w64], dy64)
     add, add64 = rnd((B, Cin, H, W), tdt, gen)

@@ -55,6 +55,10 @@ SIGNATURES = {
     "vamd_fold_partials": (_i, [_p, _i, _i, _i, _p, _p]),
     "vamd_conv2d_dgrad": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
     "vamd_conv2d_dgrad_workspace": (_z, [_d]),
+    "vamd_conv2d_fwd_up4_supported": (_i, [_d]),
+    "vamd_conv2d_fwd_up4_stats_parts": (_i, [_d]),
+    "vamd_conv2d_fwd_up4": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "vamd_repack_weight_up4_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "vamd_conv2d_dgrad_up4_supported": (_i, [_d]),
     "vamd_conv2d_dgrad_up4": (_i, [_d, _p, _p, _p, _p, _p]),
     "vamd_repack_weight_up4": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -167,6 +167,34 @@ int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, 
     return conv_dgrad_direct(g, d->dtype, dy, w_t, add, dx, as_stream(stream));
 }
 
+int vamd_conv2d_fwd_up4_supported(const vamd_conv_desc* d) {
+    ConvGeom g;
+    if (conv_geom(d, &g, "vamd_conv2d_fwd_up4_supported")) return 0;
+    return (d->algo == kAuto || d->algo == kMfma) && conv_fwd_up4_mfma_supported(g, d->dtype) ? 1 : 0;
+}
+
+int vamd_conv2d_fwd_up4_stats_parts(const vamd_conv_desc* d) {
+    ConvGeom g;
+    if (conv_geom(d, &g, "vamd_conv2d_fwd_up4_stats_parts")) return 0;
+    return conv_fwd_up4_mfma_supported(g, d->dtype) ? conv_fwd_up4_mfma_stats_parts(g) : 0;
+}
+
+int vamd_conv2d_fwd_up4(const vamd_conv_desc* d, const void* x, const void* w_up4, const float* bias,
+                        const float* temb, const void* residual, const void* residual2, void* y, float* stats,
+                        void* stream) {
+    ConvGeom g;
+    int rc = conv_geom(d, &g, "vamd_conv2d_fwd_up4");
+    if (rc) return rc;
+    VAMD_REQUIRE(x && w_up4 && y, "vamd_conv2d_fwd_up4: null tensor");
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w_up4 % 16 == 0 && (uintptr_t)y % 16 == 0 &&
+                     (uintptr_t)residual % 16 == 0 && (uintptr_t)residual2 % 16 == 0,
+                 "vamd_conv2d_fwd_up4: tensors must be 16-byte aligned");
+    if (!conv_fwd_up4_mfma_supported(g, d->dtype))
+        return fail(VAMD_EUNSUPPORTED, "vamd_conv2d_fwd_up4: needs an upsampling 3x3 descriptor the MFMA path covers (Cin=%d Cout=%d up=%d)",
+                    g.Cin, g.Cout, g.up);
+    return conv_fwd_up4_mfma(g, d->dtype, x, w_up4, bias, temb, residual, residual2, y, stats, as_stream(stream));
+}
+
 int vamd_conv2d_dgrad_up4_supported(const vamd_conv_desc* d) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_dgrad_up4_supported")) return 0;

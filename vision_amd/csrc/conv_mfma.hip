@@ -55,7 +55,8 @@ struct Gather {
     int ldx;               // elements between consecutive stored pixels (Cin unless rows are padded)
     int He, We;            // valid range of the tap coordinate u = ho*stride + r - pad
     int Ho, Wo;            // extents that m enumerates
-    int k, stride, pad;
+    int k, stride, pad;    // pad: rows; padw: columns (equal except for the classes of an upsampling forward)
+    int padw;
     int shift;             // 1: stored row = u >> 1 (nearest 2x upsample folded into the gather)
     int M, Ktot;           // rows, and (tap rows)*(tap columns)*Cin
     FastDiv div_howo, div_wo;
@@ -482,7 +483,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
             const uint32_t ho = fdiv(rem, gp.div_wo);
             const int h0 = (int)ho * gp.stride - gp.pad;
-            const int w0 = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad;
+            const int w0 = (int)(rem - ho * gp.Wo) * gp.stride - gp.padw;
             a_h0[i] = h0;
             a_w0[i] = w0;
             a_base[i] = UP ? (int)b * gp.Hin * gp.Win * gp.ldx : (((int)b * gp.Hin + h0) * gp.Win + w0) * gp.ldx;
@@ -840,7 +841,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             const uint32_t rem = m - b * (uint32_t)(gp.Ho * gp.Wo);
             const uint32_t ho = fdiv(rem, gp.div_wo);
             const int h0 = (int)ho * gp.stride - gp.pad;
-            const int w0 = (int)(rem - ho * gp.Wo) * gp.stride - gp.pad;
+            const int w0 = (int)(rem - ho * gp.Wo) * gp.stride - gp.padw;
             a_h0[i] = h0;
             a_w0[i] = w0;
             a_base[i] = UP ? (int)b * gp.Hin * gp.Win * gp.ldx : (((int)b * gp.Hin + h0) * gp.Win + w0) * gp.ldx;
@@ -1619,7 +1620,7 @@ static Gather make_gather(int Hin, int Win, int Cin, int He, int We, int Ho, int
                           int pad, int shift, int64_t M) {
     Gather g;
     g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.ldx = Cin; g.He = He; g.We = We; g.Ho = Ho; g.Wo = Wo;
-    g.k = k; g.stride = stride; g.pad = pad; g.shift = shift;
+    g.k = k; g.stride = stride; g.pad = pad; g.padw = pad; g.shift = shift;
     g.M = (int)M; g.Ktot = k * k * Cin;
     g.div_howo = make_fastdiv((uint32_t)(Ho * Wo));
     g.div_wo = make_fastdiv((uint32_t)Wo);
@@ -1668,6 +1669,36 @@ static bool nt_wide(int BN, int64_t M, int batch, int n_tiles) {
     return ((M + 255) / 256) * batch * n_tiles >= min_tiles;
 }
 
+// Block ranges of a class set.  A tile costs its K-steps plus a fixed part (set-up, epilogue) worth
+// about `ovh` reduction elements; every class gets the fewest workgroups per column tile that finish
+// it within a common time budget, the smallest budget for which all of them fit on the chip at once.
+static int plan_class_blocks(ClassSet& cs, int N, int n_tiles, int bm, int slots_per_column, double* flops) {
+    static const int ovh = [] { const char* e = getenv("VAMD_CLASS_OVH"); return e ? atoi(e) : 256; }();
+    int64_t cost[4], hi = 0;
+    for (int c = 0; c < cs.ncls; ++c) {
+        cs.m_tiles[c] = (cs.g[c].M + bm - 1) / bm;
+        cost[c] = cs.g[c].Ktot + ovh;
+        if (cost[c] * cs.m_tiles[c] > hi) hi = cost[c] * cs.m_tiles[c];
+        if (flops) *flops += 2.0 * cs.g[c].M * N * cs.g[c].Ktot;
+    }
+    auto groups_for = [&](int c, int64_t budget) {
+        int64_t per = budget / cost[c];
+        if (per < 1) per = 1;
+        return (int)((cs.m_tiles[c] + per - 1) / per);
+    };
+    int64_t lo = 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        int need = 0;
+        for (int c = 0; c < cs.ncls; ++c) need += groups_for(c, mid);
+        if (need <= slots_per_column) hi = mid; else lo = mid + 1;
+    }
+    cs.first_block[0] = 0;
+    for (int c = 0; c < 4; ++c)
+        cs.first_block[c + 1] = cs.first_block[c] + (c < cs.ncls ? groups_for(c, lo) * n_tiles : 0);
+    return cs.first_block[4];
+}
+
 template <typename T, int BN, bool UP>
 static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
                      void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st,
@@ -1675,37 +1706,9 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
     constexpr int LDS_PIPE = 2 * (kBM * kRowBytes + BN * kRowBytes);
     ClassSet cs;
     cs.ncls = 0;
-    // a class set: block ranges in proportion to the classes' work, tile counts for the tile height used
     auto plan_classes = [&](int bm, int slots_per_column, double* flops) {
         cs = *classes;
-        // a tile costs its K-steps plus a fixed part (set-up, epilogue) worth about `ovh` reduction elements;
-        // every class gets the fewest workgroups per column tile that finish it within a common time budget,
-        // the smallest budget for which all of them fit on the chip at once
-        static const int ovh = [] { const char* e = getenv("VAMD_CLASS_OVH"); return e ? atoi(e) : 256; }();
-        int64_t cost[4], hi = 0;
-        for (int c = 0; c < cs.ncls; ++c) {
-            cs.m_tiles[c] = (cs.g[c].M + bm - 1) / bm;
-            cost[c] = cs.g[c].Ktot + ovh;
-            if (cost[c] * cs.m_tiles[c] > hi) hi = cost[c] * cs.m_tiles[c];
-            *flops += 2.0 * cs.g[c].M * N * cs.g[c].Ktot;
-        }
-        auto groups_for = [&](int c, int64_t budget) {
-            int64_t per = budget / cost[c];
-            if (per < 1) per = 1;
-            return (int)((cs.m_tiles[c] + per - 1) / per);
-        };
-        int64_t lo = 1;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) / 2;
-            int need = 0;
-            for (int c = 0; c < cs.ncls; ++c) need += groups_for(c, mid);
-            if (need <= slots_per_column) hi = mid; else lo = mid + 1;
-        }
-        const int n_tiles_ = (N + BN - 1) / BN;
-        cs.first_block[0] = 0;
-        for (int c = 0; c < 4; ++c)
-            cs.first_block[c + 1] = cs.first_block[c] + (c < cs.ncls ? groups_for(c, lo) * n_tiles_ : 0);
-        return cs.first_block[4];
+        return plan_class_blocks(cs, N, (N + BN - 1) / BN, bm, slots_per_column, flops);
     };
     constexpr int LDS_EPI = kBM * (BN + 4) * 4;
     constexpr int LDS = LDS_PIPE > LDS_EPI ? LDS_PIPE : LDS_EPI;
@@ -1737,7 +1740,10 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
             const int row_tiles = mw_tiles * batch;
             int blocks = ntp_row_groups(row_tiles, n_tiles, 1) * n_tiles;
             double flops = classes ? 0.0 : 2.0 * gp.M * N * gp.Ktot * batch;
-            if (classes) blocks = plan_classes(256, 256 / n_tiles > 0 ? 256 / n_tiles : 1, &flops);
+            if (classes) {
+                blocks = plan_classes(256, 256 / n_tiles > 0 ? 256 / n_tiles : 1, &flops);
+                for (int c = 0; c < cs.ncls; ++c) cs.stats_off[c] = (int64_t)(cs.first_block[c] / n_tiles) * N * 2;
+            }
             TimedLaunch timed(TIMED_NT, flops, st);
             if (ep.stats)
                 hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, true>), dim3(blocks), dim3(512), LDS_W, st, gp,
@@ -1762,6 +1768,7 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
     if (classes) {
         const int per_column = 256 * ntp_per_cu(BN) / n_tiles;
         blocks = plan_classes(kBM, per_column > 0 ? per_column : 1, &flops);
+        for (int c = 0; c < cs.ncls; ++c) cs.stats_off[c] = (int64_t)(cs.first_block[c] / n_tiles) * N * 2;
     }
     TimedLaunch timed(TIMED_NT, flops, st);
     if (ep.stats)
@@ -1855,6 +1862,52 @@ int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, co
     Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats};
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
     return run_nt<float>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
+}
+
+// Forward of (nearest 2x upsample -> 3x3 conv, pad 1) without touching an upsampled pixel twice: output
+// pixel (2i+ph, 2j+pw) reads the 2x2 stored neighbourhood rows i-1+ph .. i+ph, columns j-1+pw .. j+pw
+// through the class filter Weff[ph][pw] (conv taps that fall on the same stored pixel summed:
+// ph = 0: {0}, {1,2};  ph = 1: {0,1}, {2}).  Four 2x2 convolutions with an output scatter of step 2
+// in one launch: 16 taps per stored pixel instead of 36.  `w4` is [4 classes][Cout][2][2][Cin]
+// (vamd_repack_weight_up4_fwd).
+static void fwd_up4_classes(const ConvGeom& g, ClassSet& set) {
+    set.ncls = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            Gather gp = make_gather(g.H, g.W, g.Cin, g.H, g.W, g.H, g.W, 2, 1, 1 - ph, 0, (int64_t)g.B * g.H * g.W);
+            gp.padw = 1 - pw;
+            gp.oH = g.Ho; gp.oW = g.Wo; gp.ostep = 2; gp.oph = ph; gp.opw = pw;
+            set.g[set.ncls] = gp;
+            set.w_off[set.ncls] = (int64_t)set.ncls * g.Cout * 4 * g.Cin;
+            set.stats_off[set.ncls] = 0;
+            ++set.ncls;
+        }
+}
+
+bool conv_fwd_up4_mfma_supported(const ConvGeom& g, int dtype) {
+    static const int on = [] { const char* e = getenv("VAMD_FWD_UP4"); return e ? atoi(e) : 1; }();
+    if (!on || !g.up || g.k != 3 || g.stride != 1 || g.pad != 1 || nt_classic()) return false;
+    return nt_shape_ok(g.Cin, g.Cout, (int64_t)g.B * g.H * g.W, dtype) && 4 * g.Cin >= (dtype == VAMD_BF16 ? 64 : 32);
+}
+
+int conv_fwd_up4_mfma_stats_parts(const ConvGeom& g) {
+    ClassSet set;
+    fwd_up4_classes(g, set);
+    const int BN = g.Cout <= 64 ? 64 : 128;
+    const int n_tiles = (g.Cout + BN - 1) / BN;
+    const bool wide = nt_wide(BN, set.g[0].M, 1, n_tiles);
+    const int per_column = wide ? 256 / n_tiles : 256 * ntp_per_cu(BN) / n_tiles;
+    return plan_class_blocks(set, g.Cout, n_tiles, wide ? 256 : kBM, per_column > 0 ? per_column : 1, nullptr) / n_tiles;
+}
+
+int conv_fwd_up4_mfma(const ConvGeom& g, int dtype, const void* x, const void* w4, const float* bias,
+                      const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st) {
+    ClassSet set;
+    fwd_up4_classes(g, set);
+    Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats};
+    const int ldw = 4 * g.Cin;
+    if (dtype == VAMD_BF16) return run_nt<bf16_t>(set.g[0], x, w4, g.Cout, ldw, g.Cout, ep, y, 1, 0, 0, 0, st, &set);
+    return run_nt<float>(set.g[0], x, w4, g.Cout, ldw, g.Cout, ep, y, 1, 0, 0, 0, st, &set);
 }
 
 bool conv_dgrad_mfma_supported(const ConvGeom& g, int dtype) {

@@ -54,6 +54,10 @@ bool conv_dgrad_mfma_supported(const ConvGeom& g, int dtype);
 size_t conv_dgrad_mfma_workspace(const ConvGeom& g, int dtype);
 int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt, const void* add,
                     void* dx, void* workspace, size_t workspace_bytes, hipStream_t st);
+bool conv_fwd_up4_mfma_supported(const ConvGeom& g, int dtype);
+int conv_fwd_up4_mfma_stats_parts(const ConvGeom& g);
+int conv_fwd_up4_mfma(const ConvGeom& g, int dtype, const void* x, const void* w4, const float* bias,
+                      const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st);
 bool conv_dgrad_up4_mfma_supported(const ConvGeom& g, int dtype);
 int conv_dgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void* w4, const void* add, void* dx,
                         hipStream_t st);

@@ -455,6 +455,32 @@ __global__ void repack_weight_up4_kernel(const float* __restrict__ w, T* __restr
     }
 }
 
+// Class filters of the forward of (nearest 2x upsample -> 3x3 conv): class (ph, pw), tap (a, b) sums
+// the conv taps that read the same stored pixel (ph = 0: {0}, {1,2}; ph = 1: {0,1}, {2}).
+// w [O][I][3][3] fp32 -> w4 [ph*2+pw][O][a][b][I] in T.
+template <typename T>
+__global__ void repack_weight_up4_fwd_kernel(const float* __restrict__ w, T* __restrict__ w4, int O, int I) {
+    const int64_t total = (int64_t)4 * O * 4 * I;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % I);
+        int64_t rest = idx / I;
+        const int bq = (int)(rest % 2); rest /= 2;
+        const int aq = (int)(rest % 2); rest /= 2;
+        const int o = (int)(rest % O);
+        const int cls = (int)(rest / O);
+        const int ph = cls >> 1, pw = cls & 1;
+        // ph = 0: a = 0 -> {0}, a = 1 -> {1,2};  ph = 1: a = 0 -> {0,1}, a = 1 -> {2}
+        const int r_lo = ph == 0 ? (aq == 0 ? 0 : 1) : (aq == 0 ? 0 : 2), r_hi = ph == 0 ? (aq == 0 ? 0 : 2) : (aq == 0 ? 1 : 2);
+        const int s_lo = pw == 0 ? (bq == 0 ? 0 : 1) : (bq == 0 ? 0 : 2), s_hi = pw == 0 ? (bq == 0 ? 0 : 2) : (bq == 0 ? 1 : 2);
+        const float* src = w + ((int64_t)o * I + i) * 9;
+        float sum = 0.f;
+        for (int r = r_lo; r <= r_hi; ++r)
+            for (int q = s_lo; q <= s_hi; ++q) sum += src[r * 3 + q];
+        w4[idx] = from_f<T>(sum);
+    }
+}
+
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwk, float* __restrict__ dw, int O,
                                     int I, int k) {
     const int64_t total = (int64_t)O * I * k * k;
@@ -725,6 +751,17 @@ int vamd_repack_weight_up4(const float* w, void* w4, int Cout, int Cin, int dtyp
                            (T*)w4, Cout, Cin);
     });
     VAMD_LAUNCH_OK("vamd_repack_weight_up4");
+    return 0;
+}
+
+int vamd_repack_weight_up4_fwd(const float* w, void* w4, int Cout, int Cin, int dtype, void* stream) {
+    VAMD_REQUIRE(w && w4 && Cout > 0 && Cin > 0, "vamd_repack_weight_up4_fwd: bad argument");
+    const int64_t total = (int64_t)16 * Cout * Cin;
+    VAMD_DISPATCH(dtype, "vamd_repack_weight_up4_fwd", {
+        hipLaunchKernelGGL(repack_weight_up4_fwd_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), w,
+                           (T*)w4, Cout, Cin);
+    });
+    VAMD_LAUNCH_OK("vamd_repack_weight_up4_fwd");
     return 0;
 }
 

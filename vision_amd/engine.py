@@ -46,6 +46,8 @@ class _Conv:
         self.wd = torch.empty((cin, k, k, cout), dtype=eng.dtype, device=eng.device)
         # upsampling convs: combined 4x4 stride-2 filter of the input gradient (filled by repack_up4)
         self.wd4 = torch.empty((cin, 4, 4, cout), dtype=eng.dtype, device=eng.device) if up and k == 3 else None
+        # ... and the four 2x2 class filters of their forward (one per output parity)
+        self.wf4 = torch.empty((4, cout, 2, 2, cin), dtype=eng.dtype, device=eng.device) if up and k == 3 else None
         self._descs: Dict[tuple, ConvDesc] = {}
 
     def repack(self):
@@ -55,6 +57,7 @@ class _Conv:
     def repack_up4(self):
         if self.wd4 is not None:
             call("vamd_repack_weight_up4", _ptr(self.w), _ptr(self.wd4), self.cout, self.cin, self.eng.dt, _stream())
+            call("vamd_repack_weight_up4_fwd", _ptr(self.w), _ptr(self.wf4), self.cout, self.cin, self.eng.dt, _stream())
 
     def desc(self, B, H, W) -> ConvDesc:
         key = (B, H, W)
@@ -94,9 +97,17 @@ class _Conv:
         e = self.eng
         y = torch.empty((B, Ho, Wo, self.cout), dtype=e.dtype, device=x.device)
         d = self.desc(B, H, W)
-        nparts = lib.vamd_conv2d_stats_parts(C.byref(d)) if want_stats else 0
+        up4 = self.wf4 is not None and lib.vamd_conv2d_fwd_up4_supported(C.byref(d))
+        if up4:
+            nparts = lib.vamd_conv2d_fwd_up4_stats_parts(C.byref(d)) if want_stats else 0
+        else:
+            nparts = lib.vamd_conv2d_stats_parts(C.byref(d)) if want_stats else 0
         ev = self._timed(0, B, H, W)
-        if nparts > 0:
+        if up4:
+            part = torch.empty((nparts, self.cout, 2), dtype=torch.float32, device=x.device) if nparts > 0 else None
+            call("vamd_conv2d_fwd_up4", C.byref(d), _ptr(x), _ptr(self.wf4), _ptr(self.b) if bias else None,
+                 _ptr(temb), _ptr(res), _ptr(res2), _ptr(y), _ptr(part), _stream())
+        elif nparts > 0:
             part = torch.empty((nparts, self.cout, 2), dtype=torch.float32, device=x.device)
             call("vamd_conv2d_fwd_stats", C.byref(d), _ptr(x), _ptr(self.wf), _ptr(self.b) if bias else None,
                  _ptr(temb), _ptr(res), _ptr(res2), _ptr(y), _ptr(part), _stream())
