@@ -1669,6 +1669,16 @@ static bool nt_wide(int BN, int64_t M, int batch, int n_tiles) {
     return ((M + 255) / 256) * batch * n_tiles >= min_tiles;
 }
 
+// The launch-timing records count ALGORITHMIC FLOPs: what the reference's operator does (2*M*N*K of the
+// convolution as written in the model).  The combined-filter forms of the upsampling conv execute
+// 16/36 of that; their host functions announce the operator's count here for the next launch.
+static thread_local double t_nominal_flops = 0.0;
+static double take_flops(double executed) {
+    const double f = t_nominal_flops > 0.0 ? t_nominal_flops : executed;
+    t_nominal_flops = 0.0;
+    return f;
+}
+
 // Block ranges of a class set.  A tile costs its K-steps plus a fixed part (set-up, epilogue) worth
 // about `ovh` reduction elements; every class gets the fewest workgroups per column tile that finish
 // it within a common time budget, the smallest budget for which all of them fit on the chip at once.
@@ -1744,7 +1754,7 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
                 blocks = plan_classes(256, 256 / n_tiles > 0 ? 256 / n_tiles : 1, &flops);
                 for (int c = 0; c < cs.ncls; ++c) cs.stats_off[c] = (int64_t)(cs.first_block[c] / n_tiles) * N * 2;
             }
-            TimedLaunch timed(TIMED_NT, flops, st);
+            TimedLaunch timed(TIMED_NT, take_flops(flops), st);
             if (ep.stats)
                 hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, true>), dim3(blocks), dim3(512), LDS_W, st, gp,
                                    x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
@@ -1770,7 +1780,7 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
         blocks = plan_classes(kBM, per_column > 0 ? per_column : 1, &flops);
         for (int c = 0; c < cs.ncls; ++c) cs.stats_off[c] = (int64_t)(cs.first_block[c] / n_tiles) * N * 2;
     }
-    TimedLaunch timed(TIMED_NT, flops, st);
+    TimedLaunch timed(TIMED_NT, take_flops(flops), st);
     if (ep.stats)
         hipLaunchKernelGGL((conv_ntp_mfma_kernel<T, BN, UP, true>), dim3(blocks), dim3(256), LDS_PIPE, st, gp, x,
                            w, N, ldw, ldc, ep, y, m_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
@@ -1807,7 +1817,7 @@ static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ld
     const int n_tiles = N / 256, mw_tiles = (gp.M + 255) / 256;
     const int row_tiles = mw_tiles * batch;
     const int groups = ntp_row_groups(row_tiles, n_tiles, 1);
-    TimedLaunch timed(TIMED_NT, 2.0 * gp.M * N * gp.Ktot * batch, st);
+    TimedLaunch timed(TIMED_NT, take_flops(2.0 * gp.M * N * gp.Ktot * batch), st);
     ClassSet cs;
     cs.ncls = 0;
     if (ep.stats)
@@ -1904,6 +1914,7 @@ int conv_fwd_up4_mfma(const ConvGeom& g, int dtype, const void* x, const void* w
                       const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st) {
     ClassSet set;
     fwd_up4_classes(g, set);
+    t_nominal_flops = 2.0 * g.M * g.Cout * 9.0 * g.Cin;
     Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats};
     const int ldw = 4 * g.Cin;
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(set.g[0], x, w4, g.Cout, ldw, g.Cout, ep, y, 1, 0, 0, 0, st, &set);
@@ -2050,6 +2061,7 @@ bool conv_dgrad_up4_mfma_supported(const ConvGeom& g, int dtype) {
 int conv_dgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void* w4, const void* add, void* dx,
                         hipStream_t st) {
     Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, g.H, g.W, 4, 2, 1, 0, (int64_t)g.B * g.H * g.W);
+    t_nominal_flops = 2.0 * g.M * g.Cout * 9.0 * g.Cin;
     Epilogue ep{nullptr, nullptr, add, nullptr, 1.0f, 0, nullptr};
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, dy, w4, g.Cin, gp.Ktot, g.Cin, ep, dx, 1, 0, 0, 0, st);
     return run_nt<float>(gp, dy, w4, g.Cin, gp.Ktot, g.Cin, ep, dx, 1, 0, 0, 0, st);
@@ -2177,7 +2189,7 @@ static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int
     int slices = 1, steps_per = total_steps;
     if (out_mode == 0) tn_split(n_tiles * f_tiles, total_steps, &slices, &steps_per);
     dim3 grid(n_tiles * f_tiles * slices, 1, batch);
-    TimedLaunch timed(TIMED_TN, 2.0 * gp.M * N * gp.Ktot * batch, st);
+    TimedLaunch timed(TIMED_TN, take_flops(2.0 * gp.M * N * gp.Ktot * batch), st);
     hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
                        f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode);
     VAMD_LAUNCH_OK("conv_tn_mfma");
@@ -2298,6 +2310,7 @@ int conv_wgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void
     float* parts = reinterpret_cast<float*>(workspace);
     float* bias_parts = parts + (size_t)slices * dgn;      // [slices][16 * Cout]
     float* dg = bias_parts + (size_t)slices * F;
+    t_nominal_flops = 2.0 * g.M * g.Cout * 9.0 * g.Cin;
     int rc;
     if (dtype == VAMD_BF16)
         rc = launch_tn<bf16_t>(gp, (const bf16_t*)x, (const bf16_t*)dy, g.Cin, g.Cin, F, parts, 1, 0, 0, 0, 0, nullptr, 1.f, dbias ? bias_parts : nullptr, 2, st);
