@@ -3,7 +3,10 @@
     python tests/perf_conv_gpu.py [case ...]      case = B,H,W,Cin,Cout,k,stride,up[,algo]
 
 Prints microseconds per call and the achieved TFLOP/s / GB/s for forward, dgrad and wgrad.
+PERF_EPI is a bit mask of epilogue work for the forward: 1 time embedding, 2 shortcut, 4 skip, 8 BatchNorm
+statistics; with any bit set the input gradient accumulates into an existing gradient.
 """
+import os
 import ctypes as C
 import sys
 
@@ -57,8 +60,19 @@ def main():
         ws = torch.empty(max(nb1, nb2, 16), dtype=torch.uint8, device=DEV)
         flops = 2.0 * B * Ho * Wo * Cout * Cin * k * k
         io = 2.0 * (x.numel() + y.numel())
-        t_f = timeit(lambda: call("vamd_conv2d_fwd", C.byref(d), x.data_ptr(), wf.data_ptr(), bias.data_ptr(), None, None, None, y.data_ptr(), st))
-        t_d = timeit(lambda: call("vamd_conv2d_dgrad", C.byref(d), dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), ws.data_ptr(), nb1, st))
+        epi = int(os.environ.get("PERF_EPI", "0"))
+        if epi:
+            nparts = max(lib.vamd_conv2d_stats_parts(C.byref(d)), 1)
+            part = torch.empty((nparts, Cout, 2), device=DEV)
+            temb = torch.randn((B, Cout), device=DEV)
+            res, res2, add = torch.randn_like(y), torch.randn_like(y), torch.randn_like(dx)
+            sel = lambda bit, t: t.data_ptr() if epi & bit else None
+            t_f = timeit(lambda: call("vamd_conv2d_fwd_stats", C.byref(d), x.data_ptr(), wf.data_ptr(), bias.data_ptr(), sel(1, temb),
+                                      sel(2, res), sel(4, res2), y.data_ptr(), sel(8, part), st))
+            t_d = timeit(lambda: call("vamd_conv2d_dgrad", C.byref(d), dy.data_ptr(), wd.data_ptr(), add.data_ptr(), dx.data_ptr(), ws.data_ptr(), nb1, st))
+        else:
+            t_f = timeit(lambda: call("vamd_conv2d_fwd", C.byref(d), x.data_ptr(), wf.data_ptr(), bias.data_ptr(), None, None, None, y.data_ptr(), st))
+            t_d = timeit(lambda: call("vamd_conv2d_dgrad", C.byref(d), dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), ws.data_ptr(), nb1, st))
         t_w = timeit(lambda: call("vamd_conv2d_wgrad", C.byref(d), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dbias.data_ptr(), ws.data_ptr(), nb2, st))
         row = "  ".join("%s %8.1f us %7.1f TF %6.0f GB/s" % (n, t, flops / t / 1e6, io / t / 1e3)
                         for n, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)))

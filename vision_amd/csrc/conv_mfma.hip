@@ -123,6 +123,158 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// Epilogue of the persistent kernels for the four pixel tiles a lane holds (rows m_first + 16*i, channels
+// nb .. nb + 4*NT - 1): y = alpha*acc + temb[image] + res + res2, rounded to T, stored, and (STATS) added
+// to the lane's per-channel sums.  Every load of a term is issued before the first use of any of them
+// and before any store: written row by row, the loads of a row could not move above the previous
+// row's store (the pointers may alias as far as the compiler knows), so a tile paid one memory
+// latency per 16-byte piece instead of one per term.  The sums land in the accumulators, which are
+// re-initialised for the next tile anyway; the order of the additions is temb, res, res2.
+template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT>
+__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[NT][4], float* s1, float* s2, const Gather& gp,
+                                              const float* temb, const void* res, const void* res2, float alpha,
+                                              int out_f32, void* yout, int N, int ldc, int64_t zoff,
+                                              uint32_t m_first, int nb) {
+    static_assert(C0 % 8 == 0 && CW % 8 == 0 && C0 + CW <= 4 * NT, "whole 16-byte pieces of the lane's channels");
+    constexpr int CH = 16 / (int)sizeof(T);               // channels per 16-byte piece of T: 8 (bf16) or 4
+    constexpr int NP = CW / CH;                           // pieces per row and lane
+    constexpr int J0 = C0 / 4, NJ = CW / 4;               // accumulator (channel tile) range
+    nb += C0;
+    int64_t offs[4];
+    uint32_t bimg[4];
+    bool valid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t m = m_first + 16 * i;
+        valid[i] = m < (uint32_t)gp.M;
+        bimg[i] = 0;
+        int64_t orow = m;
+        if (gp.ostep || temb) {
+            bimg[i] = fdiv(m, gp.div_howo);
+            if (gp.ostep) {
+                const uint32_t rem = m - bimg[i] * (uint32_t)(gp.Ho * gp.Wo);
+                const uint32_t ho = fdiv(rem, gp.div_wo);
+                const uint32_t wo = rem - ho * gp.Wo;
+                orow = ((int64_t)bimg[i] * gp.oH + ho * gp.ostep + gp.oph) * gp.oW + wo * gp.ostep + gp.opw;
+            }
+        }
+        offs[i] = zoff + orow * ldc + nb;
+    }
+    if (out_f32) {                                     // fp32 outputs of a bf16 product (attention scores)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!valid[i]) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = nb + 4 * j;
+                // a trailing partial group is written whole: its extra columns are exact zeros
+                // (their filter rows were never loaded) and ldc leaves room for them
+                if (n < N && n + 4 <= ldc)
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yout) + offs[i] + 4 * j) =
+                        make_float4(acc[J0 + j][i][0] * alpha, acc[J0 + j][i][1] * alpha, acc[J0 + j][i][2] * alpha,
+                                    acc[J0 + j][i][3] * alpha);
+            }
+        }
+        return;
+    }
+    bool piece_ok[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) piece_ok[p] = nb + p * CH < N && nb + p * CH + CH <= ldc;
+    const T* r1 = reinterpret_cast<const T*>(res ? res : res2);
+    const T* r2 = reinterpret_cast<const T*>(res ? res2 : nullptr);
+    // ---- issue: time embedding of the first row's image, first residual
+    float tv[CW];
+#pragma unroll
+    for (int e = 0; e < CW; ++e) tv[e] = 0.f;
+    if (temb && valid[0]) {                            // rows ascend: an invalid first row means no valid row
+        const float* tp = temb + (int64_t)bimg[0] * N + nb;
+#pragma unroll
+        for (int e = 0; e < CW; e += 4) {
+            if (nb + e + 4 <= N) {
+                const float4 t4 = *reinterpret_cast<const float4*>(tp + e);
+                tv[e] = t4.x; tv[e + 1] = t4.y; tv[e + 2] = t4.z; tv[e + 3] = t4.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tv[e + r] = nb + e + r < N ? tp[e + r] : 0.f;
+            }
+        }
+    }
+    Vec16<T> rv[4][NP];
+    if (r1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                if (valid[i] && piece_ok[p]) rv[i][p] = *reinterpret_cast<const Vec16<T>*>(r1 + offs[i] + p * CH);
+    }
+    // ---- use
+    if (alpha != 1.f) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[J0 + j][i] *= alpha;
+    }
+    if (temb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (bimg[i] == bimg[0]) {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) acc[J0 + (e >> 2)][i][e & 3] += tv[e];
+            } else if (valid[i]) {                        // the tile crosses into the next image: rare
+                const float* tp = temb + (int64_t)bimg[i] * N + nb;
+#pragma unroll
+                for (int e = 0; e < CW; ++e)
+                    if (nb + e < N) acc[J0 + (e >> 2)][i][e & 3] += tp[e];
+            }
+        }
+    }
+    if (r1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                if (valid[i] && piece_ok[p]) {
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) acc[J0 + ((p * CH + e) >> 2)][i][e & 3] += to_f(rv[i][p].v[e]);
+                }
+    }
+    if (r2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                if (valid[i] && piece_ok[p]) rv[i][p] = *reinterpret_cast<const Vec16<T>*>(r2 + offs[i] + p * CH);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                if (valid[i] && piece_ok[p]) {
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) acc[J0 + ((p * CH + e) >> 2)][i][e & 3] += to_f(rv[i][p].v[e]);
+                }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!valid[i]) continue;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (!piece_ok[p]) continue;
+            Vec16<T> ov;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(acc[J0 + ((p * CH + e) >> 2)][i][e & 3]);
+            *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + offs[i] + p * CH) = ov;
+            if constexpr (STATS) {                        // statistics of the rounded values a later pass would read
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const float q = to_f(ov.v[e]);
+                    s1[p * CH + e] += q;
+                    s2[p * CH + e] = fmaf(q, q, s2[p * CH + e]);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int BN, bool UP>
 __global__ void __launch_bounds__(256, 2)
 conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
@@ -604,81 +756,8 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     };
     auto write_tile = [&](int row_tile) {
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
-        const T* res = reinterpret_cast<const T*>(ep.res);
-        const T* res2 = reinterpret_cast<const T*>(ep.res2);
-        constexpr int CH = 16 / (int)sizeof(T);           // channels per 16-byte piece of T: 8 (bf16) or 4
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t m = mt * kBM + wm * 64 + i * 16 + frow;
-            if (m >= (uint32_t)gp.M) continue;
-            uint32_t bimg = 0;
-            int64_t orow = m;
-            if (gp.ostep || ep.temb) {
-                bimg = fdiv(m, gp.div_howo);
-                if (gp.ostep) {
-                    const uint32_t rem = m - bimg * (uint32_t)(gp.Ho * gp.Wo);
-                    const uint32_t ho = fdiv(rem, gp.div_wo);
-                    const uint32_t wo = rem - ho * gp.Wo;
-                    orow = ((int64_t)bimg * gp.oH + ho * gp.ostep + gp.oph) * gp.oW + wo * gp.ostep + gp.opw;
-                }
-            }
-            const int64_t off = (int64_t)z * strideC + orow * ldc + nb;
-            if (ep.out_f32) {                             // fp32 outputs of a bf16 product (attention scores)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = nb + 4 * j;
-                    // a trailing partial group is written whole: its extra columns are exact zeros
-                    // (their filter rows were never loaded) and ldc leaves room for them
-                    if (n < N && n + 4 <= ldc)
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yout) + off + 4 * j) =
-                            make_float4(acc[j][i][0] * ep.alpha, acc[j][i][1] * ep.alpha, acc[j][i][2] * ep.alpha, acc[j][i][3] * ep.alpha);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int ch = 0; ch < CPL; ch += CH) {         // one 16-byte piece of the output row
-                const int n = nb + ch;
-                if (n >= N || n + CH > ldc) continue;
-                float v[CH];
-#pragma unroll
-                for (int e = 0; e < CH; ++e) v[e] = acc[(ch + e) >> 2][i][e & 3] * ep.alpha;
-                if (ep.temb) {
-                    const float* tp = ep.temb + (int64_t)bimg * N + n;
-                    if (n + CH <= N) {
-#pragma unroll
-                        for (int e = 0; e < CH; e += 4) {
-                            const float4 t4 = *reinterpret_cast<const float4*>(tp + e);
-                            v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < CH; ++e) if (n + e < N) v[e] += tp[e];
-                    }
-                }
-                if (res) {
-                    const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res + off + ch);
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
-                }
-                if (res2) {
-                    const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res2 + off + ch);
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
-                }
-                Vec16<T> ov;
-#pragma unroll
-                for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(v[e]);
-                *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + off + ch) = ov;
-                if constexpr (STATS) {                    // statistics of the rounded values a later pass would read
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) {
-                        const float q = to_f(ov.v[e]);
-                        s1[ch + e] += q;
-                        s2[ch + e] = fmaf(q, q, s2[ch + e]);
-                    }
-                }
-            }
-        }
+        epilogue_rows<T, NT, STATS>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC,
+                                    (uint32_t)(mt * kBM + wm * 64 + frow), nb);
     };
 
     const int nk = (gp.Ktot + KSTEP - 1) / KSTEP;
@@ -953,144 +1032,24 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     };
     auto write_tile = [&](int row_tile) {
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
-        const T* res = reinterpret_cast<const T*>(ep.res);
-        const T* res2 = reinterpret_cast<const T*>(ep.res2);
-        constexpr int CH = 16 / (int)sizeof(T);           // channels per 16-byte piece of T: 8 (bf16) or 4
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t m = mt * BM + wm * 64 + i * 16 + frow;
-            if (m >= (uint32_t)gp.M) continue;
-            uint32_t bimg = 0;
-            int64_t orow = m;
-            if (gp.ostep || ep.temb) {
-                bimg = fdiv(m, gp.div_howo);
-                if (gp.ostep) {
-                    const uint32_t rem = m - bimg * (uint32_t)(gp.Ho * gp.Wo);
-                    const uint32_t ho = fdiv(rem, gp.div_wo);
-                    const uint32_t wo = rem - ho * gp.Wo;
-                    orow = ((int64_t)bimg * gp.oH + ho * gp.ostep + gp.oph) * gp.oW + wo * gp.ostep + gp.opw;
-                }
-            }
-            const int64_t off = (int64_t)z * strideC + orow * ldc + nb;
-            if (ep.out_f32) {                             // fp32 outputs of a bf16 product (attention scores)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = nb + 4 * j;
-                    // a trailing partial group is written whole: its extra columns are exact zeros
-                    // (their filter rows were never loaded) and ldc leaves room for them
-                    if (n < N && n + 4 <= ldc)
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yout) + off + 4 * j) =
-                            make_float4(acc[j][i][0] * ep.alpha, acc[j][i][1] * ep.alpha, acc[j][i][2] * ep.alpha, acc[j][i][3] * ep.alpha);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int ch = 0; ch < CPL; ch += CH) {         // one 16-byte piece of the output row
-                const int n = nb + ch;
-                if (n >= N || n + CH > ldc) continue;
-                float v[CH];
-#pragma unroll
-                for (int e = 0; e < CH; ++e) v[e] = acc[(ch + e) >> 2][i][e & 3] * ep.alpha;
-                if (ep.temb) {
-                    const float* tp = ep.temb + (int64_t)bimg * N + n;
-                    if (n + CH <= N) {
-#pragma unroll
-                        for (int e = 0; e < CH; e += 4) {
-                            const float4 t4 = *reinterpret_cast<const float4*>(tp + e);
-                            v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < CH; ++e) if (n + e < N) v[e] += tp[e];
-                    }
-                }
-                if (res) {
-                    const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res + off + ch);
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
-                }
-                if (res2) {
-                    const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res2 + off + ch);
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
-                }
-                Vec16<T> ov;
-#pragma unroll
-                for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(v[e]);
-                *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + off + ch) = ov;
-                if constexpr (STATS_REG) {                // statistics of the rounded values a later pass would read
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) {
-                        const float q = to_f(ov.v[e]);
-                        s1[ch + e] += q;
-                        s2[ch + e] = fmaf(q, q, s2[ch + e]);
-                    }
-                }
-            }
-        }
+        epilogue_rows<T, NT, STATS_REG>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC,
+                                        (uint32_t)(mt * BM + wm * 64 + frow), nb);
     };
 
-    // the same outputs with the channel piece as the outer loop, so that only 2 x CH sums are live
-    auto write_tile_stats_lds = [&](int row_tile) {
+    // the 256-channel tile: the lane's 32 channels in two halves, so that only 16 sums and one half's
+    // loads are live next to the 128 accumulators
+    auto write_half = [&](int row_tile, auto half) {
+        constexpr int H = decltype(half)::value;
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
-        const T* res = reinterpret_cast<const T*>(ep.res);
-        const T* res2 = reinterpret_cast<const T*>(ep.res2);
-        constexpr int CH = 16 / (int)sizeof(T);
-        int64_t offs[4];
-        uint32_t bimgs[4];
-        bool valid[4];
+        float t1[16], t2[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t m = mt * BM + wm * 64 + i * 16 + frow;
-            valid[i] = m < (uint32_t)gp.M;
-            bimgs[i] = ep.temb ? fdiv(m, gp.div_howo) : 0u;
-            offs[i] = (int64_t)z * strideC + (int64_t)m * ldc + nb;
-        }
+        for (int e = 0; e < 16; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+        epilogue_rows<T, NT, STATS_LDS, (NT == 8 ? 16 * H : 0), (NT == 8 ? 16 : 4 * NT)>(
+            acc, t1, t2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC,
+            (uint32_t)(mt * BM + wm * 64 + frow), nb);
+        if constexpr (STATS_LDS) {
 #pragma unroll
-        for (int ch = 0; ch < CPL; ch += CH) {
-            const int n = nb + ch;
-            float t1[CH], t2[CH];
-#pragma unroll
-            for (int e = 0; e < CH; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
-            if (n < N && n + CH <= ldc) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (!valid[i]) continue;
-                    float v[CH];
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) v[e] = acc[(ch + e) >> 2][i][e & 3] * ep.alpha;
-                    if (ep.temb) {
-                        const float* tp = ep.temb + (int64_t)bimgs[i] * N + n;
-#pragma unroll
-                        for (int e = 0; e < CH; e += 4) {
-                            const float4 t4 = *reinterpret_cast<const float4*>(tp + e);
-                            v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
-                        }
-                    }
-                    if (res) {
-                        const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res + offs[i] + ch);
-#pragma unroll
-                        for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
-                    }
-                    if (res2) {
-                        const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res2 + offs[i] + ch);
-#pragma unroll
-                        for (int e = 0; e < CH; ++e) v[e] += to_f(rv.v[e]);
-                    }
-                    Vec16<T> ov;
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(v[e]);
-                    *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + offs[i] + ch) = ov;
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) {
-                        const float q = to_f(ov.v[e]);
-                        t1[e] += q;
-                        t2[e] = fmaf(q, q, t2[e]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < CH; ++e) {
+            for (int e = 0; e < 16; ++e) {
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) {
                     t1[e] += __shfl_xor(t1[e], o, 64);
@@ -1098,14 +1057,18 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
                 }
             }
             if (frow == 0) {
-                float* slot = sred + ((wm * BN) + wn * (BN / 2) + fgrp * CPL + ch) * 2;
+                float* slot = sred + ((wm * BN) + wn * (BN / 2) + fgrp * CPL + 16 * H) * 2;
 #pragma unroll
-                for (int e = 0; e < CH; ++e) {
+                for (int e = 0; e < 16; ++e) {
                     slot[2 * e] += t1[e];
                     slot[2 * e + 1] += t2[e];
                 }
             }
         }
+    };
+    auto write_tile_pieces = [&](int row_tile) {
+        write_half(row_tile, std::integral_constant<int, 0>{});
+        write_half(row_tile, std::integral_constant<int, 1>{});
     };
 
     const int nk = (gp.Ktot + KSTEP - 1) / KSTEP;
@@ -1146,8 +1109,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
                 }
                 mma(fa, fb);
                 if (k == nk - 1) {
-                    if constexpr (STATS_LDS) write_tile_stats_lds(cur);
-                    else write_tile(cur);
+                    write_tile_pieces(cur);
                     init_acc();
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1839,7 +1801,8 @@ static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw
         return launch_nt<T, 128, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
     }
     if constexpr (sizeof(T) == 2) {
-        if (nt_wide256(N, gp.M, batch, sizeof(T), gp.Ktot, gp.shift != 0)) {
+        // the 256-channel tile's epilogue writes rows in place and in T only
+        if (!gp.ostep && !ep.out_f32 && nt_wide256(N, gp.M, batch, sizeof(T), gp.Ktot, gp.shift != 0)) {
             if (gp.shift) return launch_ntw256<T, true>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
             return launch_ntw256<T, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
         }
