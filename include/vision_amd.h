@@ -183,6 +183,18 @@ int vamd_scale_shift_act(const void* x, const float* scale, const float* shift, 
 int vamd_bn_bwd_finalize(const float* partial, int nchunk, int C, int64_t count,
                          const float* scale, float* dgamma, float* dbeta, float* cA, float* cB,
                          float* cC, void* stream);
+/* BatchNorm backward statistics with the rows grouped per image, and a finalise that also returns
+ * dsum[b][c] = sum over the pixels of image b of dx[b][.][c] (and dsum_total[c], may be NULL, its sum
+ * over b) without reading dx: `partial` holds B * nchunk * C * 3 floats (sums of gz, gz*xhat and
+ * xhat per image), nchunk = vamd_stats_chunks(HW, B); scale/shift/mean/rstd are the batch's [C].
+ * dsum is the gradient of the projected time embedding that ResNetBlock adds per image and channel
+ * to the tensor this BatchNorm normalises (models/ddpm.py:79-82), dsum_total that of conv1's bias. */
+int vamd_bn_bwd_stats_img(const void* dy, const void* x, const void* mask, const float* scale,
+                          const float* shift, const float* mean, const float* rstd, float slope,
+                          float* partial, int B, int64_t HW, int C, int dtype, void* stream);
+int vamd_bn_bwd_finalize_img(const float* partial, int nchunk, int B, int C, int64_t HW, const float* scale,
+                             float* dgamma, float* dbeta, float* cA, float* cB, float* cC, float* dsum,
+                             float* dsum_total, void* stream);
 /* Backward finalise for GroupNorm (coefficients are [B][C]). */
 int vamd_gn_bwd_finalize(const float* partial, int nchunk, int B, int C, int groups, int64_t HW,
                          const float* gamma, const float* rstd, float* dgamma, float* dbeta,

@@ -329,6 +329,23 @@ def test_batchnorm_act_fwd_bwd(shape, dts):
     assert relerr(out[0], gg) < 2e-4 and relerr(out[1], gb) < 2e-4
     assert relerr(dx.permute(0, 3, 1, 2), gx + add64) < TOL_OUT[dts]
 
+    # statistics grouped per image: the same coefficients and parameter gradients, and the per-image
+    # channel sums of dx (exact ones, of the fp64 gradient) without a pass over dx
+    nck = lib.vamd_stats_chunks(H * W, B)
+    part3 = torch.empty((B, nck, Cc, 3), dtype=torch.float32, device=DEV)
+    call("vamd_bn_bwd_stats_img", P(dyn), P(x), P(maskn), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01,
+         P(part3), B, H * W, Cc, dt, S())
+    out2 = torch.empty((5, Cc), dtype=torch.float32, device=DEV)
+    dsum = torch.empty((B, Cc), dtype=torch.float32, device=DEV)
+    dtot = torch.empty((Cc,), dtype=torch.float32, device=DEV)
+    call("vamd_bn_bwd_finalize_img", P(part3), nck, B, Cc, H * W, P(coef[0]), P(out2[0]), P(out2[1]), P(out2[2]),
+         P(out2[3]), P(out2[4]), P(dsum), P(dtot), S())
+    assert relerr(out2, out) < 1e-5
+    ref_sum = gx.sum(dim=(2, 3))
+    scale_ref = float(gx.abs().sum(dim=(2, 3)).max())      # the sums cancel: measure against the summed magnitudes
+    assert float((dsum.double().cpu() - ref_sum).abs().max()) < (2e-5 if dts == "f32" else 2e-2) * scale_ref
+    assert float((dtot.double().cpu() - ref_sum.sum(0)).abs().max()) < (2e-5 if dts == "f32" else 2e-2) * scale_ref * B
+
     # eval mode: running statistics
     call("vamd_bn_finalize", None, 0, Cc, 0, P(gm), P(bt), P(rmd), P(rvd), None, 0.1, 1e-5, 0,
          P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), S())

@@ -50,12 +50,15 @@ struct NormBwdArgs {
 };
 
 // MODE 0: accumulates (x, x*x).  MODE 1: accumulates (gz, gz*xhat) for the backward pass.
+// MODE 2: BatchNorm backward with the rows grouped per image: group g is image g, the coefficients are
+// the batch's (one set), and a third sum, xhat, is kept: with it the per-image channel sums of dx
+// follow from the partial sums alone (bn_bwd_finalize_img_kernel), without another pass over dx.
 // Thread layout: tc = C/VEC lanes across channels, tr = 256/tc lanes across rows.
 template <typename T, int VEC, int MODE>
 __global__ void __launch_bounds__(kStatsBlock)
 chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ partial, int64_t R,
                   int C, int nchunk) {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [tr][C][2]
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [tr][C][2 or 3]
     const int g = blockIdx.y, chunk = blockIdx.x;
     const int cvec = C / VEC;
     const int tc = cvec;                       // host guarantees cvec <= 256
@@ -65,19 +68,21 @@ chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ pa
     const int64_t r0 = (int64_t)chunk * rows_per;
     int64_t r1 = r0 + rows_per;
     if (r1 > R) r1 = R;
-    float s1[VEC], s2[VEC];
+    constexpr int NS = MODE == 2 ? 3 : 2;      // sums per channel
+    float s1[VEC], s2[VEC], s3[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = 0.f;
+    for (int j = 0; j < VEC; ++j) s1[j] = s2[j] = s3[j] = 0.f;
     if (rl < tr) {
         const int c0 = cl * VEC;
         float sc[VEC], sh[VEC], mu[VEC], rs[VEC];
-        if (MODE == 1) {
+        if (MODE != 0) {
+            const int64_t cg = MODE == 2 ? 0 : (int64_t)g * C;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                sc[j] = a.scale[(int64_t)g * C + c0 + j];
-                sh[j] = a.shift[(int64_t)g * C + c0 + j];
-                mu[j] = a.mean[(int64_t)g * C + c0 + j];
-                rs[j] = a.rstd[(int64_t)g * C + c0 + j];
+                sc[j] = a.scale[cg + c0 + j];
+                sh[j] = a.shift[cg + c0 + j];
+                mu[j] = a.mean[cg + c0 + j];
+                rs[j] = a.rstd[cg + c0 + j];
             }
         }
         const T* dy = (const T*)a.dy;
@@ -86,13 +91,13 @@ chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ pa
             const int64_t off = ((int64_t)g * R + r) * C + c0;
             if (VEC > 1) {
                 *reinterpret_cast<Vec16<T>*>(xv) = *reinterpret_cast<const Vec16<T>*>(x + off);
-                if (MODE == 1) {
+                if (MODE != 0) {
                     *reinterpret_cast<Vec16<T>*>(dv) = *reinterpret_cast<const Vec16<T>*>(dy + off);
                     if (mk) *reinterpret_cast<Vec16<T>*>(mv) = *reinterpret_cast<const Vec16<T>*>(mk + off);
                 }
             } else {
                 xv[0] = x[off];
-                if (MODE == 1) {
+                if (MODE != 0) {
                     dv[0] = dy[off];
                     if (mk) mv[0] = mk[off];
                 }
@@ -113,6 +118,7 @@ chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ pa
                     const float xh = (xf - mu[j]) * rs[j];
                     s1[j] += gz;
                     s2[j] = fmaf(gz, xh, s2[j]);
+                    if (MODE == 2) s3[j] += xh;
                 }
             }
         };
@@ -137,15 +143,16 @@ chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ pa
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            red[((int64_t)rl * C + c0 + j) * 2 + 0] = s1[j];
-            red[((int64_t)rl * C + c0 + j) * 2 + 1] = s2[j];
+            red[((int64_t)rl * C + c0 + j) * NS + 0] = s1[j];
+            red[((int64_t)rl * C + c0 + j) * NS + 1] = s2[j];
+            if (MODE == 2) red[((int64_t)rl * C + c0 + j) * NS + 2] = s3[j];
         }
     }
     __syncthreads();
-    float* out = partial + ((int64_t)g * nchunk + chunk) * C * 2;
-    for (int i = threadIdx.x; i < C * 2; i += kStatsBlock) {
+    float* out = partial + ((int64_t)g * nchunk + chunk) * C * NS;
+    for (int i = threadIdx.x; i < C * NS; i += kStatsBlock) {
         float acc = 0.f;
-        for (int r = 0; r < tr; ++r) acc += red[(int64_t)r * C * 2 + i];
+        for (int r = 0; r < tr; ++r) acc += red[(int64_t)r * C * NS + i];
         out[i] = acc;
     }
 }
@@ -231,6 +238,50 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nc
     cA[c] = (float)sc;
     cB[c] = (float)(-sc * s1 / count);
     cC[c] = (float)(-sc * s2 / count);
+}
+
+// BatchNorm backward from per-image partial sums [B][nchunk][C][3] = (gz, gz*xhat, xhat): the usual
+// coefficients and parameter gradients from the totals, and, because dx = cA*gz + cC*xhat + cB is
+// affine in the summed quantities, the per-image channel sums of dx (the gradient of a per-image,
+// per-channel additive term of the normalised tensor's producer) and their total.  One wave per
+// channel, lane = image (strided), fixed order of additions.
+__global__ void bn_bwd_finalize_img_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
+                                           double hw, const float* __restrict__ scale, float* dgamma,
+                                           float* dbeta, float* cA, float* cB, float* cC,
+                                           float* __restrict__ dsum, float* __restrict__ dsum_total) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double t1 = 0.0, t2 = 0.0;
+    for (int b = lane; b < B; b += 64) {
+        for (int k = 0; k < nchunk; ++k) {
+            const float* q = partial + (((int64_t)b * nchunk + k) * C + c) * 3;
+            t1 += (double)q[0];
+            t2 += (double)q[1];
+        }
+    }
+    const double s1 = wave_sum_d(t1), s2 = wave_sum_d(t2);
+    const double count = hw * B;
+    const double sc = (double)scale[c];
+    const double a = sc, bq = -sc * s1 / count, cq = -sc * s2 / count;
+    double tot = 0.0;
+    for (int b = lane; b < B; b += 64) {
+        double g1 = 0.0, g3 = 0.0;
+        for (int k = 0; k < nchunk; ++k) {
+            const float* q = partial + (((int64_t)b * nchunk + k) * C + c) * 3;
+            g1 += (double)q[0];
+            g3 += (double)q[2];
+        }
+        const double d = a * g1 + cq * g3 + hw * bq;
+        dsum[(int64_t)b * C + c] = (float)d;
+        tot += d;
+    }
+    tot = wave_sum_d(tot);
+    if (lane != 0) return;
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    cA[c] = (float)a;
+    cB[c] = (float)bq;
+    cC[c] = (float)cq;
+    if (dsum_total) dsum_total[c] = (float)tot;
 }
 
 // thread per (b, group): coefficients
@@ -416,13 +467,13 @@ static int launch_stats(const char* name, const T* x, NormBwdArgs a, float* part
     const bool vec = (C % VEC == 0) && (C / VEC <= kStatsBlock);
     if (vec) {
         const int tr = kStatsBlock / (C / VEC);
-        const size_t lds = (size_t)tr * C * 2 * sizeof(float);
+        const size_t lds = (size_t)tr * C * (MODE == 2 ? 3 : 2) * sizeof(float);
         hipLaunchKernelGGL((chan_stats_kernel<T, VEC, MODE>), grid, dim3(kStatsBlock), lds, st, x, a,
                            partial, R, C, nchunk);
     } else {
         if (C > kStatsBlock) return fail(VAMD_EUNSUPPORTED, "%s: C=%d not a multiple of %d and > 256", name, C, VEC);
         const int tr = kStatsBlock / C;
-        const size_t lds = (size_t)tr * C * 2 * sizeof(float);
+        const size_t lds = (size_t)tr * C * (MODE == 2 ? 3 : 2) * sizeof(float);
         hipLaunchKernelGGL((chan_stats_kernel<T, 1, MODE>), grid, dim3(kStatsBlock), lds, st, x, a,
                            partial, R, C, nchunk);
     }
@@ -462,6 +513,33 @@ int vamd_norm_bwd_stats(const void* dy, const void* x, const void* mask, const f
         if (rc) return rc;
     });
     VAMD_LAUNCH_OK("vamd_norm_bwd_stats");
+    return 0;
+}
+
+int vamd_bn_bwd_stats_img(const void* dy, const void* x, const void* mask, const float* scale,
+                          const float* shift, const float* mean, const float* rstd, float slope,
+                          float* partial, int B, int64_t HW, int C, int dtype, void* stream) {
+    VAMD_REQUIRE(dy && x && scale && shift && mean && rstd && partial, "vamd_bn_bwd_stats_img: null pointer");
+    VAMD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && C > 0, "vamd_bn_bwd_stats_img: bad shape");
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)mask % 16 == 0,
+                 "vamd_bn_bwd_stats_img: tensors must be 16-byte aligned");
+    NormBwdArgs a{dy, mask, scale, shift, mean, rstd, slope};
+    VAMD_DISPATCH(dtype, "vamd_bn_bwd_stats_img", {
+        int rc = launch_stats<T, 2>("vamd_bn_bwd_stats_img", (const T*)x, a, partial, B, HW, C, as_stream(stream));
+        if (rc) return rc;
+    });
+    VAMD_LAUNCH_OK("vamd_bn_bwd_stats_img");
+    return 0;
+}
+
+int vamd_bn_bwd_finalize_img(const float* partial, int nchunk, int B, int C, int64_t HW, const float* scale,
+                             float* dgamma, float* dbeta, float* cA, float* cB, float* cC, float* dsum,
+                             float* dsum_total, void* stream) {
+    VAMD_REQUIRE(partial && scale && dgamma && dbeta && cA && cB && cC && dsum && nchunk > 0 && B > 0 && C > 0 && HW > 0,
+                 "vamd_bn_bwd_finalize_img: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_img_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, nchunk, B, C,
+                       (double)HW, scale, dgamma, dbeta, cA, cB, cC, dsum, dsum_total);
+    VAMD_LAUNCH_OK("vamd_bn_bwd_finalize_img");
     return 0;
 }
 

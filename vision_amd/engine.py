@@ -218,17 +218,30 @@ class _Norm:
              Cc, e.dt, _stream())
         return y, coef
 
-    def bwd(self, dy, x, coef, mask=None, add=None, add2=None, need_dx=True):
+    def bwd(self, dy, x, coef, mask=None, add=None, add2=None, need_dx=True, img_sums=None):
+        """img_sums = (dsum [B][C], total [C] or None): BatchNorm only; filled with the per-image channel
+        sums of dx (and their sum over the batch) from the statistics pass, without reading dx."""
         B, H, W, Cc = x.shape
         e, dev = self.eng, x.device
         G, R = (1, B * H * W) if self.bn else (B, H * W)
         sc, sh, mu, rs = coef[0], coef[1], coef[2], coef[3]
-        nchunk = lib.vamd_stats_chunks(R, G)
-        part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=dev)
-        call("vamd_norm_bwd_stats", _ptr(dy), _ptr(x), _ptr(mask), _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs),
-             self.slope, _ptr(part), G, R, Cc, e.dt, _stream())
         abc = torch.empty((3, G, Cc), dtype=torch.float32, device=dev)
-        if self.bn:
+        if img_sums is not None:
+            nchunk = lib.vamd_stats_chunks(H * W, B)
+            part = torch.empty((B, nchunk, Cc, 3), dtype=torch.float32, device=dev)
+            call("vamd_bn_bwd_stats_img", _ptr(dy), _ptr(x), _ptr(mask), _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs),
+                 self.slope, _ptr(part), B, H * W, Cc, e.dt, _stream())
+            call("vamd_bn_bwd_finalize_img", _ptr(part), nchunk, B, Cc, H * W, _ptr(sc), _ptr(self.ggamma),
+                 _ptr(self.gbeta), _ptr(abc[0]), _ptr(abc[1]), _ptr(abc[2]), _ptr(img_sums[0]), _ptr(img_sums[1]),
+                 _stream())
+        else:
+            nchunk = lib.vamd_stats_chunks(R, G)
+            part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=dev)
+            call("vamd_norm_bwd_stats", _ptr(dy), _ptr(x), _ptr(mask), _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs),
+                 self.slope, _ptr(part), G, R, Cc, e.dt, _stream())
+        if img_sums is not None:
+            pass
+        elif self.bn:
             call("vamd_bn_bwd_finalize", _ptr(part), nchunk, Cc, R, _ptr(sc), _ptr(self.ggamma),
                  _ptr(self.gbeta), _ptr(abc[0]), _ptr(abc[1]), _ptr(abc[2]), _stream())
         else:
@@ -242,16 +255,6 @@ class _Norm:
              self.slope, _ptr(abc[0]), _ptr(abc[1]), _ptr(abc[2]), _ptr(add), _ptr(add2), _ptr(dx), G, R,
              Cc, e.dt, _stream())
         return dx
-
-
-def _chan_sums(eng, t, per_image: bool):
-    """Per-channel sums of an NHWC tensor: returns (per_image [B][C] or None, total [C])."""
-    B, H, W, Cc = t.shape
-    G, R = (B, H * W) if per_image else (1, B * H * W)
-    nchunk = lib.vamd_stats_chunks(R, G)
-    part = torch.empty((G, nchunk, Cc, 2), dtype=torch.float32, device=t.device)
-    call("vamd_chan_stats", _ptr(t), _ptr(part), G, R, Cc, eng.dt, _stream())
-    return part, nchunk, G
 
 
 class _ResBlock:
@@ -294,11 +297,10 @@ class _ResBlock:
             self.short.gb.copy_(self.conv2.gb)
             self.short.wgrad(dy, x, bias=False)
             dxs = self.short.dgrad(dy, x.shape) if need_dx else None
-        dh1 = self.bn2.bwd(da2, h1, coef2, mask)
-        # d(projected temb)[b][c] = sum over pixels of dh1; conv1 bias gradient = its sum over b
-        part, nchunk, G = _chan_sums(e, dh1, True)
-        dtproj = torch.empty((G, self.spec.cout), dtype=torch.float32, device=dy.device)
-        call("vamd_sum_finalize", _ptr(part), nchunk, G, self.spec.cout, _ptr(dtproj), _ptr(self.conv1.gb), _stream())
+        # d(projected temb)[b][c] = sum over pixels of dh1; conv1 bias gradient = its sum over b: both
+        # come out of the BatchNorm backward's statistics pass (dh1 is affine in the summed terms)
+        dtproj = torch.empty((dy.shape[0], self.spec.cout), dtype=torch.float32, device=dy.device)
+        dh1 = self.bn2.bwd(da2, h1, coef2, mask, img_sums=(dtproj, self.conv1.gb))
         self.temb.bwd(temb, dtproj, dx=dtemb, accumulate=True)
         # conv1's bias feeds a train-mode BatchNorm, whose mean subtraction cancels it: the
         # gradient is exactly zero (dh1 sums to zero over the batch) and is not computed
