@@ -315,23 +315,52 @@ linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
     dx[idx] = accumulate ? dx[idx] + v : v;
 }
 
-// thread per (o, i): dW[o][i] = sum_b dy[b][o] act(x[b][i]); i == 0 also writes dbias[o]
-__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                     float* __restrict__ dW, float* __restrict__ dbias, int B,
-                                     int I, int O, int act_in, float slope) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= O * I) return;
-    const int o = idx / I, i = idx - o * I;
-    float acc = 0.f, accb = 0.f;
-    for (int b = 0; b < B; ++b) {
-        float v = x[(int64_t)b * I + i];
-        if (act_in) v = leaky(v, slope);
-        const float g = dy[(int64_t)b * O + o];
-        acc = fmaf(g, v, acc);
-        accb += g;
+// dW[o][i] = sum_b dy[b][o] act(x[b][i]); the i == 0 column also writes dbias[o].  A block owns 16
+// outputs o x 64 inputs i and walks the batch in slabs of 64 rows staged in LDS (the sum runs over b
+// in ascending order, as a scalar loop would).
+__global__ void __launch_bounds__(256)
+linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                     float* __restrict__ dW, float* __restrict__ dbias, int B,
+                     int I, int O, int act_in, float slope) {
+    __shared__ float xs[64][64];
+    __shared__ float dys[64][16];
+    const int itiles = (I + 63) / 64;
+    const int ot = blockIdx.x / itiles, it = blockIdx.x - ot * itiles;
+    const int o0 = ot * 16, i0 = it * 64;
+    const int il = threadIdx.x & 63, ol = threadIdx.x >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int nb = B - b0 < 64 ? B - b0 : 64;
+        for (int idx = threadIdx.x; idx < nb * 64; idx += 256) {
+            const int b = idx >> 6, i = idx & 63;
+            float v = i0 + i < I ? x[(int64_t)(b0 + b) * I + i0 + i] : 0.f;
+            if (act_in) v = leaky(v, slope);
+            xs[b][i] = v;
+        }
+        for (int idx = threadIdx.x; idx < nb * 16; idx += 256) {
+            const int b = idx >> 4, o = idx & 15;
+            dys[b][o] = o0 + o < O ? dy[(int64_t)(b0 + b) * O + o0 + o] : 0.f;
+        }
+        __syncthreads();
+        for (int b = 0; b < nb; ++b) {
+            const float v = xs[b][il];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g = dys[b][ol * 4 + q];
+                acc[q] = fmaf(g, v, acc[q]);
+                accb[q] += g;
+            }
+        }
+        __syncthreads();
     }
-    dW[idx] = acc;
-    if (i == 0 && dbias) dbias[o] = accb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = o0 + ol * 4 + q, i = i0 + il;
+        if (o < O && i < I) {
+            dW[(int64_t)o * I + i] = acc[q];
+            if (i == 0 && dbias) dbias[o] = accb[q];
+        }
+    }
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -697,8 +726,7 @@ int vamd_linear_bwd(const float* x, const float* W, const float* dy, float* dx, 
         hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(total), dim3(256), 0,
                            as_stream(stream), x, W, dy, dx, B, I, O, act_in, slope, accumulate_dx);
     }
-    const int total = O * I;
-    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((total + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(((O + 15) / 16) * ((I + 63) / 64)), dim3(256), 0,
                        as_stream(stream), x, dy, dW, dbias, B, I, O, act_in, slope);
     VAMD_LAUNCH_OK("vamd_linear_bwd");
     return 0;
