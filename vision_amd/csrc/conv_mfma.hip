@@ -19,7 +19,7 @@
 #include "conv_shapes.h"
 
 #ifndef VAMD_ABLATE
-#define VAMD_ABLATE 0        // 1..4 / 5..7 / 8: timing-only experiments on the wide / the 128-row / the weight-gradient kernel (results are wrong)
+#define VAMD_ABLATE 0        // 1..4, 10, 11 / 5..7 / 8: timing-only experiments on the wide / the 128-row / the weight-gradient kernel (results are wrong)
 #endif
 
 namespace vamd {
@@ -958,6 +958,9 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         unsigned char* sb = smem + buf * STAGE + A_BYTES + wave_s * 1024;
         const bool f_ok = f < gp.Ktot;
         const int wf = ((gp.wr0 + gp.wstep * tr) * gp.wk + gp.ws0 + gp.wstep * ts) * gp.Cin + c;   // == f for a plain filter
+#if VAMD_ABLATE == 11       // timing only: filter rows loaded in the first K-step of a tile alone
+        if (f < KSTEP)
+#endif
 #pragma unroll
         for (int i = 0; i < NPB; ++i) {
             load16_lds(rw, (uint32_t)(b_off[i] + wf) * (uint32_t)sizeof(T), f_ok & b_ok[i], sb + i * 8192);
@@ -1143,7 +1146,9 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             const bool issue = s_more;
             const bool last = k == nk - 1;
             read_frags(buf, 1, a1, b1);
-#if VAMD_ABLATE != 4
+#if VAMD_ABLATE == 10       // timing only: pixel loads for the first tap alone, as if a halo tile served the other eight
+            if (issue && tap == 0) stage_a(sbuf);
+#elif VAMD_ABLATE != 4
             if (issue) stage_a(sbuf);
 #endif
             mma(a0, b0);
