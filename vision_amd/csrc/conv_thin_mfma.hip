@@ -181,17 +181,48 @@ thin_out_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __r
             wf[t][hf] = p < g.Cout ? *reinterpret_cast<const bf16x8_t*>(w + ((int64_t)p * K * K + t) * Cin + hf * 32 + grp * 8)
                                    : zero8();
 
-    // B = input: column = pixel w0 + p (shifted by the tap), k = the same 8 channels
-    auto load_row = [&](int hi, bf16x8_t (&f)[K][NH]) {
+    // B = input: column = pixel w0 + p (shifted by the tap), k = the same 8 channels.  A row is loaded
+    // once (the strip's 16 pixels, plus the pixel left of it in lane p = 0 and right of it in lane
+    // p = 15); the fragments of the outer taps are the centre fragment moved one lane within the
+    // 16-lane row (DPP row_shr / row_shl, the edge lane keeps the halo pixel).  K = 3 means pad = 1.
+    constexpr int NR = K == 3 ? 2 : 1;                        // raw pieces per half: centre (, halo)
+    auto load_row = [&](int hi, bf16x8_t (&f)[NR][NH]) {
         const bool hok = (unsigned)hi < (unsigned)g.H;
+        const bf16_t* row = x + ((int64_t)b * g.H + hi) * g.W * Cin + grp * 8;
+        const int wi = w0 + p;
+        const bool ok = hok && wi < g.W;
 #pragma unroll
-        for (int s = 0; s < K; ++s) {
-            const int wi = w0 + p + s - g.pad;
-            const bool ok = hok && (unsigned)wi < (unsigned)g.W;
-            const bf16_t* src = x + (((int64_t)b * g.H + hi) * g.W + wi) * Cin + grp * 8;
+        for (int hf = 0; hf < NH; ++hf)
+            f[0][hf] = ok ? *reinterpret_cast<const bf16x8_t*>(row + (int64_t)wi * Cin + hf * 32) : zero8();
+        if constexpr (K == 3) {
+            const int wh = p == 0 ? w0 - 1 : w0 + 16;
+            const bool okh = hok && (p == 0 || p == 15) && (unsigned)wh < (unsigned)g.W;
 #pragma unroll
             for (int hf = 0; hf < NH; ++hf)
-                f[s][hf] = ok ? *reinterpret_cast<const bf16x8_t*>(src + hf * 32) : zero8();
+                f[1][hf] = okh ? *reinterpret_cast<const bf16x8_t*>(row + (int64_t)wh * Cin + hf * 32) : zero8();
+        }
+    };
+    auto shifted = [&](const bf16x8_t& c, const bf16x8_t& h, auto left) -> bf16x8_t {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        const i32x4_t ci = __builtin_bit_cast(i32x4_t, c), hi4 = __builtin_bit_cast(i32x4_t, h);
+        i32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (decltype(left)::value) o[e] = __builtin_amdgcn_update_dpp(hi4[e], ci[e], 0x111, 0xf, 0xf, false);   // row_shr:1
+            else o[e] = __builtin_amdgcn_update_dpp(hi4[e], ci[e], 0x101, 0xf, 0xf, false);                                   // row_shl:1
+        }
+        return __builtin_bit_cast(bf16x8_t, o);
+    };
+    auto expand = [&](const bf16x8_t (&raw)[NR][NH], bf16x8_t (&f)[K][NH]) {
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) {
+            if constexpr (K == 3) {
+                f[0][hf] = shifted(raw[0][hf], raw[1][hf], std::true_type{});    // pixel p - 1
+                f[1][hf] = raw[0][hf];
+                f[2][hf] = shifted(raw[0][hf], raw[1][hf], std::false_type{});   // pixel p + 1
+            } else {
+                f[0][hf] = raw[0][hf];
+            }
         }
     };
 
@@ -199,7 +230,7 @@ thin_out_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < K; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int hi_first = h0 - g.pad, hi_last = h1 - 1 + (K - 1 - g.pad);
-    bf16x8_t cur[K][NH], nxt[K][NH];
+    bf16x8_t cur[K][NH], raw[NR][NH];
     // per-lane epilogue constants (D row = output channel 4*grp + r): loads inside the row loop would
     // be younger than the next row's prefetch, and waiting for them would wait for the prefetch too
     float bt[4];
@@ -212,9 +243,9 @@ thin_out_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __r
             if (temb) bt[r] += temb[(int64_t)b * g.Cout + co];
         }
     }
-    load_row(hi_first, cur);
-#pragma unroll 1
-    for (int hi = hi_first; hi <= hi_last; ++hi) {
+    // one input row is in flight while one is consumed (a second one in flight spills registers: 2.3x slower)
+    auto row_step = [&](int hi) {
+        expand(raw, cur);
         const int hout = hi + g.pad - (K - 1);                 // the output row completed by input row hi
         const int wq = w0 + p;
         const bool store = hout >= h0 && hout < h1 && wq < g.W;
@@ -231,7 +262,7 @@ thin_out_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __r
                 }
             }
         }
-        if (hi < hi_last) load_row(hi + 1, nxt);
+        if (hi < hi_last) load_row(hi + 1, raw);
         // input row hi feeds output row hi + pad - r through filter row r; slot i = K-1-r holds
         // output row hi + pad - (K-1) + i
 #pragma unroll
@@ -251,11 +282,10 @@ thin_out_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __r
 #pragma unroll
         for (int i = 0; i + 1 < K; ++i) acc[i] = acc[i + 1];
         acc[K - 1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < K; ++s)
-#pragma unroll
-            for (int hf = 0; hf < NH; ++hf) cur[s][hf] = nxt[s][hf];
-    }
+    };
+    load_row(hi_first, raw);
+#pragma unroll 1
+    for (int hi = hi_first; hi <= hi_last; ++hi) row_step(hi);
 }
 
 // ------------------------------------------------------------------------------- thin_wgrad
@@ -523,7 +553,7 @@ int thin_in_mfma(const ConvGeom& g, const void* x, const void* w, const float* b
 
 bool thin_out_mfma_ok(const ConvGeom& g) {
     if (g.stride != 1 || g.up || g.Cout > 16) return false;
-    if (g.k == 3) return g.Cin == 32 || g.Cin == 64;
+    if (g.k == 3) return g.pad == 1 && (g.Cin == 32 || g.Cin == 64);
     if (g.k == 1) return g.Cin == 32 || g.Cin == 64 || g.Cin == 128;
     return false;
 }
