@@ -84,6 +84,18 @@ int vamd_conv2d_stats_parts(const vamd_conv_desc* d);
  * Autograd mirror of the call sites listed for vamd_conv2d_fwd. */
 int vamd_conv2d_dgrad(const vamd_conv_desc* d, const void* dy, const void* w_t, const void* add,
                       void* dx, void* workspace, size_t workspace_bytes, void* stream);
+/* conv(x; w) + conv1x1(x2; w2) + bias (+ temb + residual2) in one launch: ResNetBlock's
+ * `self.block2(h) + self.layers(x)` (models/ddpm.py:83-87) when the shortcut is a 1x1 convolution.
+ * x2 is [B][H][W][Cin2] (the block's input), w2 the packed [Cout][Cin2] shortcut filter, `bias` the
+ * SUM of both convolutions' biases; the shortcut runs as Cin2 extra reduction steps of the 3x3, so
+ * its output tensor is never written or read.  Stride 1, no upsampling, Cin and Cin2 multiples of 64
+ * (bf16) / 32 (fp32): vamd_conv2d_fwd_short_supported tells.  `stats` as in vamd_conv2d_fwd_stats,
+ * sized by vamd_conv2d_stats_parts of the same descriptor (may be NULL). */
+int vamd_conv2d_fwd_short_supported(const vamd_conv_desc* d, int Cin2);
+int vamd_conv2d_fwd_short(const vamd_conv_desc* d, const void* x, const void* w, const float* bias,
+                          const float* temb, const void* x2, const void* w2, int Cin2,
+                          const void* residual2, void* y, float* stats, void* stream);
+
 /* Forward of an upsampling descriptor (nearest 2x -> 3x3 conv, models/ddpm.py:29-41) as four 2x2
  * convolutions over the stored input, one per output parity class, in one launch: 16 taps per stored
  * pixel instead of 36.  `w_up4` is [4][Cout][2][2][Cin] from vamd_repack_weight_up4_fwd; epilogue

@@ -150,14 +150,17 @@ def _butterfly_model(compute_dtype):
     return model, cfg, sd, R
 
 
+@pytest.mark.parametrize("fuse_shortcut", [False, True], ids=["two-launch-shortcut", "shortcut-in-conv2"])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_full_resolution_model_against_oracle(mode):
+def test_full_resolution_model_against_oracle(mode, fuse_shortcut, monkeypatch):
     """224x224 butterfly UNet on 2 images against the oracle evaluated in fp64.
     Train-mode prediction: 2e-6 (fp32 compute; torch's own fp32 forward is at 2.4e-7) / 2e-2 (bf16).
     Loss: 1e-5 / 2e-2.  Gradients, global relative error: 2e-3 / 5e-2 - the L1 loss's sign() turns
     a forward rounding difference of 1e-6 into flipped gradient signs for the outputs that sit
     that close to their target, which costs ~1e-3 of the gradient norm (the oracle's own fp32
     gradient is 7e-5 away from its fp64 gradient); measured 7e-4 / 1.1e-2."""
+    import vision_amd.engine as engine_mod
+    monkeypatch.setattr(engine_mod, "FUSE_SHORTCUT", fuse_shortcut)      # opt-in path of ResNetBlock's conv2
     model, cfg, sd, R = _butterfly_model(mode)
     model.train()
     P_ = cfg["patch_size"]

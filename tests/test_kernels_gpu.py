@@ -230,6 +230,62 @@ def test_conv_fwd_dgrad_wgrad(case, dts, algo):
     assert relerr(dwk.permute(0, 3, 1, 2), gw64) < TOL_F32OUT[dts]
 
 
+SHORT_CASES = [
+    # B, H, W, Cin (of the 3x3), Cout, Cin2 (of the 1x1 shortcut), k
+    (2, 12, 12, 64, 64, 128, 3),       # 128-row tile, 64 output channels
+    (1, 20, 26, 128, 128, 64, 3),      # 256 x 128 tile
+    (1, 24, 48, 128, 128, 256, 3),
+    (2, 18, 18, 256, 256, 128, 3),     # 256 x 256 tile when forced
+    (1, 9, 11, 512, 512, 256, 3),
+    (2, 7, 9, 64, 192, 64, 3),         # partial channel tile, ragged rows
+    (2, 10, 10, 64, 64, 64, 1),        # 1x1 + 1x1
+]
+
+
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+@pytest.mark.parametrize("case", SHORT_CASES)
+def test_conv_fwd_with_shortcut_source(case, dts):
+    """conv(x; w) + conv1x1(x2; w2) in one launch against the fp64 sum and against the two-launch form."""
+    B, H, W, Cin, Cout, Cin2, k = case
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(hash(case) % 1000)
+    d = ConvDesc(B, H, W, Cin, Cout, k, 1, 1 if k == 3 else 0, 0, dt, _lib.ALGO_AUTO)
+    assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2) == 1
+    assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2 + 8) == 0
+    x, x64 = rnd((B, Cin, H, W), tdt, gen)
+    x2, x264 = rnd((B, Cin2, H, W), tdt, gen)
+    _, w64 = rnd((Cout, Cin, k, k), tdt, gen, 1.0 / math.sqrt(Cin * k * k))
+    _, w264 = rnd((Cout, Cin2, 1, 1), tdt, gen, 1.0 / math.sqrt(Cin2))
+    wf, _ = pack_weights(w64, tdt, dt)
+    wf2, _ = pack_weights(w264, tdt, dt)
+    bias = torch.randn(Cout, generator=gen)
+    temb = torch.randn(B, Cout, generator=gen)
+    res2, res264 = rnd((B, Cout, H, W), tdt, gen)
+    want = (conv_ref(x64, w64, 1, 0, k) + F.conv2d(x264, w264) + bias.double()[None, :, None, None]
+            + temb.double()[:, :, None, None] + res264)
+    xn, x2n = nhwc(x).contiguous(), nhwc(x2).contiguous()
+    nparts = lib.vamd_conv2d_stats_parts(C.byref(d))
+    assert nparts > 0
+    part = torch.full((nparts, Cout, 2), 7.0, dtype=torch.float32, device=DEV)
+    y = torch.full((B, H, W, Cout), 7.0, dtype=tdt, device=DEV)
+    call("vamd_conv2d_fwd_short", C.byref(d), P(xn), P(wf), P(bias.to(DEV)), P(temb.to(DEV)), P(x2n), P(wf2), Cin2,
+         P(nhwc(res2)), P(y), P(part), S())
+    assert relerr(y.permute(0, 3, 1, 2), want) < TOL_OUT[dts]
+    yd = y.double().cpu().reshape(-1, Cout)
+    assert relerr(part.sum(0), torch.stack([yd.sum(0), (yd * yd).sum(0)], 1)) < 1e-5
+    # without statistics and extras
+    y0 = torch.full((B, H, W, Cout), 7.0, dtype=tdt, device=DEV)
+    call("vamd_conv2d_fwd_short", C.byref(d), P(xn), P(wf), None, None, P(x2n), P(wf2), Cin2, None, P(y0), None, S())
+    assert relerr(y0.permute(0, 3, 1, 2), conv_ref(x64, w64, 1, 0, k) + F.conv2d(x264, w264)) < TOL_OUT[dts]
+    # the two-launch form rounds the shortcut to the compute dtype in between: equal to that rounding
+    d1 = ConvDesc(B, H, W, Cin2, Cout, 1, 1, 0, 0, dt, _lib.ALGO_AUTO)
+    sc = torch.empty((B, H, W, Cout), dtype=tdt, device=DEV)
+    call("vamd_conv2d_fwd", C.byref(d1), P(x2n), P(wf2), None, None, None, None, P(sc), S())
+    y1 = torch.empty_like(y0)
+    call("vamd_conv2d_fwd", C.byref(d), P(xn), P(wf), None, None, P(sc), None, P(y1), S())
+    assert relerr(y0, y1) < (1e-5 if dts == "f32" else 1e-2)
+
+
 def test_conv_rejects_bad_arguments():
     d = ConvDesc(1, 4, 4, 8, 8, 5, 1, 2, 0, _lib.F32, 0)
     x = torch.zeros(16, device=DEV)

@@ -52,6 +52,8 @@ SIGNATURES = {
     "vamd_conv2d_fwd": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vamd_conv2d_fwd_stats": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vamd_conv2d_stats_parts": (_i, [_d]),
+    "vamd_conv2d_fwd_short_supported": (_i, [_d, _i]),
+    "vamd_conv2d_fwd_short": (_i, [_d, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "vamd_fold_partials": (_i, [_p, _i, _i, _i, _p, _p]),
     "vamd_conv2d_dgrad": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
     "vamd_conv2d_dgrad_workspace": (_z, [_d]),

@@ -195,6 +195,28 @@ int vamd_conv2d_fwd_up4(const vamd_conv_desc* d, const void* x, const void* w_up
     return conv_fwd_up4_mfma(g, d->dtype, x, w_up4, bias, temb, residual, residual2, y, stats, as_stream(stream));
 }
 
+int vamd_conv2d_fwd_short_supported(const vamd_conv_desc* d, int Cin2) {
+    ConvGeom g;
+    if (conv_geom(d, &g, "vamd_conv2d_fwd_short_supported")) return 0;
+    return (d->algo == kAuto || d->algo == kMfma) && conv_fwd_short_mfma_supported(g, d->dtype, Cin2) ? 1 : 0;
+}
+
+int vamd_conv2d_fwd_short(const vamd_conv_desc* d, const void* x, const void* w, const float* bias, const float* temb,
+                          const void* x2, const void* w2, int Cin2, const void* residual2, void* y, float* stats,
+                          void* stream) {
+    ConvGeom g;
+    int rc = conv_geom(d, &g, "vamd_conv2d_fwd_short");
+    if (rc) return rc;
+    VAMD_REQUIRE(x && w && x2 && w2 && y, "vamd_conv2d_fwd_short: null tensor");
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)x2 % 16 == 0 &&
+                     (uintptr_t)w2 % 16 == 0 && (uintptr_t)residual2 % 16 == 0,
+                 "vamd_conv2d_fwd_short: tensors must be 16-byte aligned");
+    if (!(d->algo == kAuto || d->algo == kMfma) || !conv_fwd_short_mfma_supported(g, d->dtype, Cin2))
+        return fail(VAMD_EUNSUPPORTED, "vamd_conv2d_fwd_short: needs a stride-1 descriptor the MFMA path covers and channel counts "
+                    "that are multiples of %d (Cin=%d Cout=%d Cin2=%d)", d->dtype == VAMD_BF16 ? 64 : 32, g.Cin, g.Cout, Cin2);
+    return conv_fwd_short_mfma(g, d->dtype, x, w, bias, temb, x2, w2, Cin2, residual2, y, stats, as_stream(stream));
+}
+
 int vamd_conv2d_dgrad_up4_supported(const vamd_conv_desc* d) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_dgrad_up4_supported")) return 0;

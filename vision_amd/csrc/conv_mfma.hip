@@ -63,7 +63,12 @@ struct Gather {
     // Sub-filter views (stride-2 input gradient, one launch per output parity class):
     int kr, ks;            // tap rows and columns (k, k for a square filter); Ktot = kr * ks * Cin
     int wr0, ws0, wstep, wk;   // tap (tr, ts) reads filter tap (wr0 + wstep*tr, ws0 + wstep*ts) of a wk x wk filter
-    int oH, oW, ostep, oph, opw;   // ostep = 2: row (b, ho, wo) is written to pixel (b, 2*ho + oph, 2*wo + opw) of an oH x oW image
+    int oH, oW, ostep, oph, opw;   // ostep = 2: row (b, ho, wo) is written to pixel (b, 2*ho + oph, 2*wo + opw) of an oH x oW image    // Second source (gather mode 2): after the kr*ks taps the reduction runs on over Cin2 channels of the
+    // pixel itself in x2 [M][Cin2] against w2 [N][Cin2] - a 1x1 convolution of another tensor summed into
+    // the same accumulators (the shortcut of a ResNetBlock inside its conv2).  Ktot includes Cin2.
+    const void* x2;
+    const void* w2;
+    int Cin2;
 };
 
 struct Epilogue {
@@ -556,11 +561,12 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
 //     output channels, columns = pixels) and the filter rows are permuted inside the LDS tile, so
 //     every lane ends up with 4*NT consecutive channels of one pixel (no LDS pass, no barrier);
 //   * fused column statistics are kept in registers across the tiles and reduced once.
-template <typename T, int BN, bool UP, bool STATS>
+template <typename T, int BN, int GM, bool STATS>            // GM: 0 plain gather, 1 upsampling gather, 2 second source
 __global__ void __launch_bounds__(256, BN == 64 ? 3 : 2)
 conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
                      Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, int row_tiles,
                      int64_t strideA, int64_t strideB, int64_t strideC, ClassSet cs) {
+    constexpr bool UP = GM == 1, TWO = GM == 2;
     constexpr int PIECE = ElemTraits<T>::PIECE;          // elements per 16-byte piece
     constexpr int KSTEP = kRowBytes / sizeof(T);          // reduction elements per K-step
     constexpr int A_BYTES = kBM * kRowBytes;
@@ -597,7 +603,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     const int chunk = slot ^ (srow & 7);                 // logical piece held by this LDS slot
     // filter rows: LDS row R of the wave half h = R / (BN/2), q = R % (BN/2) = 16*jc + i holds
     // channel h*(BN/2) + (i>>2)*CPL + 4*jc + (i&3)
-    int b_off[BN / 32];
+    int b_off[BN / 32], b_off2[TWO ? BN / 32 : 1];
     bool b_ok[BN / 32];
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) {
@@ -606,11 +612,15 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         const int n = n0 + h * (BN / 2) + ((q & 15) >> 2) * CPL + 4 * (q >> 4) + (q & 3);
         b_ok[i] = n < N;
         b_off[i] = (b_ok[i] ? n : 0) * ldw;
+        if constexpr (TWO) b_off2[i] = (b_ok[i] ? n : 0) * gp.Cin2;
     }
     int a_base[4], a_h0[4], a_w0[4];
     uint32_t a_mask[4];
     int f, c, tr, ts, tap;
+    int a_m0 = 0;                                        // first pixel row of this thread in the tile (second source)
     __amdgpu_buffer_rsrc_t rx = make_rsrc(x), rw = make_rsrc(w);
+    const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(TWO ? gp.x2 : x), rw2 = make_rsrc(TWO ? gp.w2 : w);
+    const int ntaps = gp.kr * gp.ks;
     auto advance = [&]() {                               // branch-free: at most two taps per K-step
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -627,6 +637,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
         rx = make_rsrc(x + (int64_t)z * strideA);
         rw = make_rsrc(w + (int64_t)z * strideB);
+        a_m0 = mt * kBM + srow;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t m = mt * kBM + srow + 32 * i;
@@ -659,6 +670,17 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     auto stage_a = [&](int buf) {
         unsigned char* sa = smem + buf * STAGE + wave_s * 1024;
         const bool f_ok = f < gp.Ktot;
+        if constexpr (TWO) {
+            if (__builtin_amdgcn_readfirstlane(tap) >= ntaps) {       // uniform: channel counts are multiples of a K-step
+                const int c2 = (tap - ntaps) * gp.Cin + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = a_m0 + 32 * i;
+                    load16_lds(rx2, (uint32_t)(m * gp.Cin2 + c2) * (uint32_t)sizeof(T), f_ok & (m < gp.M), sa + i * 4096);
+                }
+                return;
+            }
+        }
         const int tapoff = (tr * gp.Win + ts) * gp.ldx + c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -673,9 +695,18 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         unsigned char* sb = smem + buf * STAGE + A_BYTES + wave_s * 1024;
         const bool f_ok = f < gp.Ktot;
         const int wf = ((gp.wr0 + gp.wstep * tr) * gp.wk + gp.ws0 + gp.wstep * ts) * gp.Cin + c;   // == f for a plain filter
+        bool second = false;
+        if constexpr (TWO) second = __builtin_amdgcn_readfirstlane(tap) >= ntaps;
+        if (second) {
+            const int c2 = (tap - ntaps) * gp.Cin + c;
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-            load16_lds(rw, (uint32_t)(b_off[i] + wf) * (uint32_t)sizeof(T), f_ok & b_ok[i], sb + i * 4096);
+            for (int i = 0; i < BN / 32; ++i)
+                load16_lds(rw2, (uint32_t)(b_off2[TWO ? i : 0] + c2) * (uint32_t)sizeof(T), f_ok & b_ok[i], sb + i * 4096);
+        } else {
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) {
+                load16_lds(rw, (uint32_t)(b_off[i] + wf) * (uint32_t)sizeof(T), f_ok & b_ok[i], sb + i * 4096);
+            }
         }
         f += KSTEP;
         c += KSTEP;
@@ -838,11 +869,12 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
 // issued two K-steps before they are read: the wait before a K-step's barrier covers the next
 // stage only, the one after it stays in flight across the barrier.  The K-steps of consecutive
 // tiles form one stream, so the ring never drains between tiles.
-template <typename T, int BN, bool UP, bool STATS>
+template <typename T, int BN, int GM, bool STATS>            // GM: 0 plain gather, 1 upsampling gather, 2 second source
 __global__ void __launch_bounds__(512, 1)
 conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
                      Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, int row_tiles,
                      int64_t strideA, int64_t strideB, int64_t strideC, ClassSet cs) {
+    constexpr bool UP = GM == 1, TWO = GM == 2;
     constexpr int PIECE = ElemTraits<T>::PIECE;          // elements per 16-byte piece
     constexpr int KSTEP = kRowBytes / sizeof(T);          // reduction elements per K-step
     constexpr int BM = 256;
@@ -882,7 +914,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     const int chunk = slot ^ (srow & 7);                 // logical piece held by this LDS slot
     // filter rows: LDS row R of the wave half h = R / (BN/2), q = R % (BN/2) = 16*jc + i holds
     // channel h*(BN/2) + (i>>2)*CPL + 4*jc + (i&3)
-    int b_off[NPB];
+    int b_off[NPB], b_off2[TWO ? NPB : 1];
     bool b_ok[NPB];
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
@@ -891,11 +923,15 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         const int n = n0 + h * (BN / 2) + ((q & 15) >> 2) * CPL + 4 * (q >> 4) + (q & 3);
         b_ok[i] = n < N;
         b_off[i] = (b_ok[i] ? n : 0) * ldw;
+        if constexpr (TWO) b_off2[i] = (b_ok[i] ? n : 0) * gp.Cin2;
     }
     int a_base[NPA], a_h0[NPA], a_w0[NPA];
     uint32_t a_mask[NPA];
     int f, c, tr, ts, tap;
+    int a_m0 = 0;                                        // first pixel row of this thread in the tile (second source)
     __amdgpu_buffer_rsrc_t rx = make_rsrc(x), rw = make_rsrc(w);
+    const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(TWO ? gp.x2 : x), rw2 = make_rsrc(TWO ? gp.w2 : w);
+    const int ntaps = gp.kr * gp.ks;
     auto advance = [&]() {                               // branch-free: at most two taps per K-step
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -912,6 +948,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
         rx = make_rsrc(x + (int64_t)z * strideA);
         rw = make_rsrc(w + (int64_t)z * strideB);
+        a_m0 = mt * BM + srow;
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const uint32_t m = mt * BM + srow + 64 * i;
@@ -944,6 +981,17 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     auto stage_a = [&](int buf) {
         unsigned char* sa = smem + buf * STAGE + wave_s * 1024;
         const bool f_ok = f < gp.Ktot;
+        if constexpr (TWO) {
+            if (__builtin_amdgcn_readfirstlane(tap) >= ntaps) {       // uniform: channel counts are multiples of a K-step
+                const int c2 = (tap - ntaps) * gp.Cin + c;
+#pragma unroll
+                for (int i = 0; i < NPA; ++i) {
+                    const int m = a_m0 + 64 * i;
+                    load16_lds(rx2, (uint32_t)(m * gp.Cin2 + c2) * (uint32_t)sizeof(T), f_ok & (m < gp.M), sa + i * 8192);
+                }
+                return;
+            }
+        }
         const int tapoff = (tr * gp.Win + ts) * gp.ldx + c;
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
@@ -958,12 +1006,22 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         unsigned char* sb = smem + buf * STAGE + A_BYTES + wave_s * 1024;
         const bool f_ok = f < gp.Ktot;
         const int wf = ((gp.wr0 + gp.wstep * tr) * gp.wk + gp.ws0 + gp.wstep * ts) * gp.Cin + c;   // == f for a plain filter
+        bool second = false;
+        if constexpr (TWO) second = __builtin_amdgcn_readfirstlane(tap) >= ntaps;
+        if (second) {
+            const int c2 = (tap - ntaps) * gp.Cin + c;
+#pragma unroll
+            for (int i = 0; i < NPB; ++i)
+                load16_lds(rw2, (uint32_t)(b_off2[TWO ? i : 0] + c2) * (uint32_t)sizeof(T), f_ok & b_ok[i], sb + i * 8192);
+        } else
 #if VAMD_ABLATE == 11       // timing only: filter rows loaded in the first K-step of a tile alone
         if (f < KSTEP)
 #endif
+        {
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) {
-            load16_lds(rw, (uint32_t)(b_off[i] + wf) * (uint32_t)sizeof(T), f_ok & b_ok[i], sb + i * 8192);
+            for (int i = 0; i < NPB; ++i) {
+                load16_lds(rw, (uint32_t)(b_off[i] + wf) * (uint32_t)sizeof(T), f_ok & b_ok[i], sb + i * 8192);
+            }
         }
         f += KSTEP;
         c += KSTEP;
@@ -1593,6 +1651,7 @@ static Gather make_gather(int Hin, int Win, int Cin, int He, int We, int Ho, int
     g.div_wo = make_fastdiv((uint32_t)Wo);
     g.kr = k; g.ks = k; g.wr0 = 0; g.ws0 = 0; g.wstep = 1; g.wk = k;
     g.oH = 0; g.oW = 0; g.ostep = 0; g.oph = 0; g.opw = 0;
+    g.x2 = nullptr; g.w2 = nullptr; g.Cin2 = 0;
     return g;
 }
 
@@ -1676,7 +1735,7 @@ static int plan_class_blocks(ClassSet& cs, int N, int n_tiles, int bm, int slots
     return cs.first_block[4];
 }
 
-template <typename T, int BN, bool UP>
+template <typename T, int BN, int UP>
 static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
                      void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st,
                      const ClassSet* classes = nullptr) {
@@ -1693,12 +1752,12 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
     if (nt_classic()) {
         static bool configured = false;
         if (!configured) {
-            int rc = set_lds_limit(conv_nt_mfma_kernel<T, BN, UP>, LDS, "conv_nt_mfma");
+            int rc = set_lds_limit(conv_nt_mfma_kernel<T, BN, UP == 1>, LDS, "conv_nt_mfma");
             if (rc) return rc;
             configured = true;
         }
         dim3 grid(m_tiles * n_tiles, 1, batch);
-        hipLaunchKernelGGL((conv_nt_mfma_kernel<T, BN, UP>), grid, dim3(256), LDS, st, gp, x, w, N, ldw, ldc, ep, y,
+        hipLaunchKernelGGL((conv_nt_mfma_kernel<T, BN, UP == 1>), grid, dim3(256), LDS, st, gp, x, w, N, ldw, ldc, ep, y,
                            m_tiles, n_tiles, sA, sB, sC);
         VAMD_LAUNCH_OK("conv_nt_mfma");
         return 0;
@@ -1770,7 +1829,7 @@ static bool nt_wide256(int N, int64_t M, int batch, size_t elem, int Ktot, bool 
     return ((M + 255) / 256) * batch * (N / 256) >= min_tiles;
 }
 
-template <typename T, bool UP>
+template <typename T, int UP>
 static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
                          void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
     constexpr int LDS_W = 2 * (256 * kRowBytes + 256 * kRowBytes) + 4 * 256 * 2 * (int)sizeof(float);   // stages + statistics slots
@@ -1804,6 +1863,15 @@ static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw
     if (classes) {                                        // class sets: stride-1 gathers without upsampling
         if (N <= 64) return launch_nt<T, 64, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
         return launch_nt<T, 128, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
+    }
+    if (gp.Cin2 > 0) {                                    // second source: stride-1 gather without upsampling
+        // tile choice by the main reduction alone, so that the statistics-parts query of the plain conv holds
+        if constexpr (sizeof(T) == 2) {
+            if (nt_wide256(N, gp.M, batch, sizeof(T), gp.Ktot - gp.Cin2, false))
+                return launch_ntw256<T, 2>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+        }
+        if (N <= 64) return launch_nt<T, 64, 2>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
+        return launch_nt<T, 128, 2>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st);
     }
     if constexpr (sizeof(T) == 2) {
         // the 256-channel tile's epilogue writes rows in place and in T only
@@ -1840,6 +1908,28 @@ int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, co
     Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats};
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
     return run_nt<float>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
+}
+
+// conv(x; w) + conv1x1(x2; w2) in one launch: the 1x1 shortcut of a ResNetBlock rides as Cin2 extra
+// reduction steps of its conv2 (no shortcut tensor is written or read back).  Stride 1, no
+// upsampling, channel counts that are multiples of a K-step so that a K-step never straddles sources.
+bool conv_fwd_short_mfma_supported(const ConvGeom& g, int dtype, int Cin2) {
+    const int kstep = dtype == VAMD_BF16 ? 64 : 32;
+    if (nt_classic() || g.up || g.stride != 1 || Cin2 <= 0 || Cin2 % kstep != 0 || g.Cin % kstep != 0) return false;
+    if ((int64_t)g.M * Cin2 >= (1ll << 30)) return false;      // 32-bit byte offsets into x2
+    return nt_shape_ok(g.Cin, g.Cout, g.M, dtype);
+}
+
+int conv_fwd_short_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
+                        const float* temb, const void* x2, const void* w2, int Cin2, const void* res2, void* y,
+                        float* stats, hipStream_t st) {
+    Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
+    const int ldw = gp.Ktot;
+    gp.x2 = x2; gp.w2 = w2; gp.Cin2 = Cin2;
+    gp.Ktot += Cin2;
+    Epilogue ep{bias, temb, nullptr, res2, 1.0f, 0, stats};
+    if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, ldw, g.Cout, ep, y, 1, 0, 0, 0, st);
+    return run_nt<float>(gp, x, w, g.Cout, ldw, g.Cout, ep, y, 1, 0, 0, 0, st);
 }
 
 // Forward of (nearest 2x upsample -> 3x3 conv, pad 1) without touching an upsampled pixel twice: output

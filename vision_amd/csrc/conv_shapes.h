@@ -54,6 +54,10 @@ bool conv_dgrad_mfma_supported(const ConvGeom& g, int dtype);
 size_t conv_dgrad_mfma_workspace(const ConvGeom& g, int dtype);
 int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt, const void* add,
                     void* dx, void* workspace, size_t workspace_bytes, hipStream_t st);
+bool conv_fwd_short_mfma_supported(const ConvGeom& g, int dtype, int Cin2);
+int conv_fwd_short_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
+                        const float* temb, const void* x2, const void* w2, int Cin2, const void* res2, void* y,
+                        float* stats, hipStream_t st);
 bool conv_fwd_up4_mfma_supported(const ConvGeom& g, int dtype);
 int conv_fwd_up4_mfma_stats_parts(const ConvGeom& g);
 int conv_fwd_up4_mfma(const ConvGeom& g, int dtype, const void* x, const void* w4, const float* bias,

@@ -12,6 +12,7 @@ the reference), with packed compute-dtype copies refreshed after every optimiser
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -124,6 +125,30 @@ class _Conv:
             e.stats_for[y.data_ptr()] = (part, nparts)
         return y
 
+    def fwd_short(self, x, short, x2, res2=None, bias_sum=None, want_stats=False):
+        """y = conv(x) + short(x2) + (both biases) (+ res2) in one launch (`short` is a 1x1 _Conv whose
+        output has this conv's shape), or None when the kernels do not cover the shape."""
+        B, H, W, _ = x.shape
+        d = self.desc(B, H, W)
+        if self.stride != 1 or self.up or not lib.vamd_conv2d_fwd_short_supported(C.byref(d), short.cin):
+            return None
+        e = self.eng
+        y = torch.empty((B, H, W, self.cout), dtype=e.dtype, device=x.device)
+        nparts = lib.vamd_conv2d_stats_parts(C.byref(d)) if want_stats else 0
+        part = torch.empty((nparts, self.cout, 2), dtype=torch.float32, device=x.device) if nparts > 0 else None
+        ev = self._timed(0, B, H, W)
+        call("vamd_conv2d_fwd_short", C.byref(d), _ptr(x), _ptr(self.wf), _ptr(bias_sum), None, _ptr(x2), _ptr(short.wf),
+             short.cin, _ptr(res2), _ptr(y), _ptr(part), _stream())
+        if ev is not None:
+            ev.record()
+        if nparts > 0:
+            if nparts > 512:
+                folded = torch.empty((128, self.cout, 2), dtype=torch.float32, device=x.device)
+                call("vamd_fold_partials", _ptr(part), nparts, 2 * self.cout, 128, _ptr(folded), _stream())
+                part, nparts = folded, 128
+            e.stats_for[y.data_ptr()] = (part, nparts)
+        return y
+
     def dgrad(self, dy, in_shape, add=None):
         B, H, W, _ = in_shape
         d = self.desc(B, H, W)
@@ -175,6 +200,9 @@ class _Linear:
         call("vamd_linear_bwd", _ptr(x), _ptr(self.w), _ptr(dy), _ptr(dx), _ptr(self.gw),
              _ptr(self.gb) if dbias else None, x.shape[0], self.cin, self.cout, self.act_in, LEAKY_SLOPE,
              int(accumulate), _stream())
+
+
+FUSE_SHORTCUT = os.environ.get("VAMD_FWD_SHORT", "0") != "0"
 
 
 class _Norm:
@@ -271,6 +299,12 @@ class _ResBlock:
         self.short = _Conv(eng, p + ".layers.0", spec.cin, spec.cout, 1) if spec.cin != spec.cout else None
         self.convs = [c for c in (self.conv1, self.conv2, self.short) if c is not None]
         self._gb_stale = False                   # conv1's bias gradient holds an eval-mode value
+        # conv2's bias + the shortcut's, for the launch that computes both convolutions (Engine.refresh)
+        self.bsum = torch.zeros(spec.cout, dtype=torch.float32, device=eng.device) if self.short is not None else None
+
+    def refresh_bias(self):
+        if self.bsum is not None:
+            torch.add(self.conv2.b, self.short.b, out=self.bsum)
 
     def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
         a1, coef1 = self.bn1.fwd(x, training)
@@ -280,8 +314,14 @@ class _ResBlock:
         if training and self.spec.dropout > 0.0:
             mask = drop_mask if drop_mask is not None else self.eng.draw_dropout(h1.shape, self.spec.dropout)
         a2, coef2 = self.bn2.fwd(h1, training, mask)
-        sc = self.short.fwd(x) if self.short is not None else x
-        y = self.conv2.fwd(a2, res=sc, res2=res2, want_stats=want_stats)
+        y = None
+        # the 1x1 shortcut as extra reduction steps of conv2: measured +0.3 % on the training step and
+        # -2.5 % on 16-image sampling batches against the two-launch form, so it is opt-in
+        if self.short is not None and FUSE_SHORTCUT:
+            y = self.conv2.fwd_short(a2, self.short, x, res2=res2, bias_sum=self.bsum, want_stats=want_stats)
+        if y is None:
+            sc = self.short.fwd(x) if self.short is not None else x
+            y = self.conv2.fwd(a2, res=sc, res2=res2, want_stats=want_stats)
         if tape is not None:
             tape.append((self, (x, a1, coef1, h1, a2, coef2, mask, temb, training)))
         return y
@@ -557,6 +597,9 @@ class Engine:
             call("vamd_repack_weights", _ptr(raw), n, blocks, self.dt, _stream())
             for c in self.all_convs():
                 c.repack_up4()
+            for layer in self.layers:
+                if isinstance(layer, _ResBlock):
+                    layer.refresh_bias()
             self._versions = vers
             self.dirty = False
 
