@@ -82,8 +82,34 @@ thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __re
 
     const int total = HT * HT * Cin;
     const int t_end = min((int)(blockIdx.x + 1) * kThinInTiles, ntiles);
+    // halo elements of this thread (the same window positions for every tile) and their prefetch registers:
+    // the next tile's window is in flight while this tile is computed and stored
+    constexpr int NPRE = (HT * HT * 4 + 255) / 256;               // Cin <= 4
+    int pyx[NPRE], pc[NPRE];
+    bf16_t pre[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        const int e = tid + 256 * q;
+        const int c = e % Cin, pp = e / Cin;
+        pyx[q] = e < total ? ((pp / HT) << 16) | (pp % HT) : -1;
+        pc[q] = c;
+    }
+    auto fetch = [&](int tile) {
+        const int tx = tile % tiles_w;
+        const int ty = (tile / tiles_w) % tiles_h;
+        const int b = tile / (tiles_w * tiles_h);
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int hi = ty * 16 + (pyx[q] >> 16) - g.pad, wi = tx * 16 + (pyx[q] & 0xffff) - g.pad;
+            bf16_t v = (bf16_t)0.f;
+            if (pyx[q] >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+                v = x[(((int64_t)b * g.H + hi) * g.W + wi) * Cin + pc[q]];
+            pre[q] = v;
+        }
+    };
     int b_prev = -1;
     f32x4_t init[NTN];
+    if ((int)blockIdx.x * kThinInTiles < t_end) fetch(blockIdx.x * kThinInTiles);
 #pragma unroll 1
     for (int tile = blockIdx.x * kThinInTiles; tile < t_end; ++tile) {
         const int tx = tile % tiles_w;
@@ -99,16 +125,11 @@ thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __re
             b_prev = b;
         }
         __syncthreads();                      // the previous tile's halo has been read by every wave
-        for (int e = tid; e < total; e += 256) {
-            const int c = e % Cin, pp = e / Cin;
-            const int xx = pp % HT, yy = pp / HT;
-            const int hi = h0 + yy - g.pad, wi = w0 + xx - g.pad;
-            bf16_t v = (bf16_t)0.f;
-            if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
-                v = x[(((int64_t)b * g.H + hi) * g.W + wi) * Cin + c];
-            halo[e] = v;
-        }
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q)
+            if (pyx[q] >= 0) halo[tid + 256 * q] = pre[q];
         __syncthreads();
+        if (tile + 1 < t_end) fetch(tile + 1);
 
 #pragma unroll 1
         for (int rr = 0; rr < 4; ++rr) {
@@ -126,6 +147,16 @@ thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __re
             const int wq = w0 + p;
             if (wq < g.W) {
                 const int64_t m = ((int64_t)b * g.H + h) * g.W + wq;
+                // every residual load before the first store (a store in between would order them)
+                Vec16<bf16_t> rv[NTN / 2], rv2[NTN / 2];
+                if (res) {
+#pragma unroll
+                    for (int ch = 0; ch < NTN / 2; ++ch) rv[ch] = *reinterpret_cast<const Vec16<bf16_t>*>(res + m * Cout + c0 + ch * 8);
+                }
+                if (res2) {
+#pragma unroll
+                    for (int ch = 0; ch < NTN / 2; ++ch) rv2[ch] = *reinterpret_cast<const Vec16<bf16_t>*>(res2 + m * Cout + c0 + ch * 8);
+                }
 #pragma unroll
                 for (int ch = 0; ch < NTN / 2; ++ch) {            // chunks of 8 channels = 16 bytes
                     float v[8];
@@ -133,14 +164,12 @@ thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __re
                     for (int e = 0; e < 8; ++e) v[e] = acc[ch * 2 + (e >> 2)][e & 3];
                     const int cc = c0 + ch * 8;
                     if (res) {
-                        const Vec16<bf16_t> rv = *reinterpret_cast<const Vec16<bf16_t>*>(res + m * Cout + cc);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += to_f(rv.v[e]);
+                        for (int e = 0; e < 8; ++e) v[e] += to_f(rv[ch].v[e]);
                     }
                     if (res2) {
-                        const Vec16<bf16_t> rv = *reinterpret_cast<const Vec16<bf16_t>*>(res2 + m * Cout + cc);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += to_f(rv.v[e]);
+                        for (int e = 0; e < 8; ++e) v[e] += to_f(rv2[ch].v[e]);
                     }
                     Vec16<bf16_t> ov;
 #pragma unroll
