@@ -2,6 +2,7 @@
 same operator on the same (dtype-rounded) inputs.  Run on the MI355X box: pytest -m gpu."""
 import ctypes as C
 import math
+import os
 
 import pytest
 import torch
@@ -79,6 +80,8 @@ CONV_CASES = [
     (1, 13, 11, 128, 192, 3, 1, 0),
     (1, 20, 26, 256, 256, 3, 1, 0),
     (2, 16, 32, 64, 64, 3, 1, 0),
+    (2, 19, 37, 64, 64, 3, 1, 0),      # ragged 8 x 32 patches of the resident-filter kernel (when forced)
+    (3, 33, 20, 64, 64, 3, 1, 0),      # ragged 16 x 16 patches
     (1, 24, 48, 128, 128, 3, 1, 0),
     (1, 8, 16, 64, 64, 3, 1, 1),
     (1, 32, 64, 64, 128, 3, 2, 0),
@@ -250,6 +253,9 @@ def test_conv_fwd_with_shortcut_source(case, dts):
     tdt, dt = DT[dts]
     gen = torch.Generator().manual_seed(hash(case) % 1000)
     d = ConvDesc(B, H, W, Cin, Cout, k, 1, 1 if k == 3 else 0, 0, dt, _lib.ALGO_AUTO)
+    if dts == "bf16" and (Cin, Cout, k) == (64, 64, 3) and os.environ.get("VAMD_C64_HALO_MIN") == "1":
+        assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2) == 0
+        pytest.skip("the resident-filter kernel is forced for this shape; it has no second source")
     assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2) == 1
     assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2 + 8) == 0
     x, x64 = rnd((B, Cin, H, W), tdt, gen)

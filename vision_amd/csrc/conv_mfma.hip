@@ -135,36 +135,17 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 // row's store (the pointers may alias as far as the compiler knows), so a tile paid one memory
 // latency per 16-byte piece instead of one per term.  The sums land in the accumulators, which are
 // re-initialised for the next tile anyway; the order of the additions is temb, res, res2.
+// Core: the four rows are given by the element offset of the lane's first channel (offs), the image
+// each belongs to (bimg, for the time embedding; ascending) and a validity flag.
 template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT>
-__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[NT][4], float* s1, float* s2, const Gather& gp,
-                                              const float* temb, const void* res, const void* res2, float alpha,
-                                              int out_f32, void* yout, int N, int ldc, int64_t zoff,
-                                              uint32_t m_first, int nb) {
+__device__ __forceinline__ void epilogue_rows_at(f32x4_t (&acc)[NT][4], float* s1, float* s2,
+                                                 const float* temb, const void* res, const void* res2, float alpha,
+                                                 int out_f32, void* yout, int N, int ldc, const int64_t (&offs)[4],
+                                                 const uint32_t (&bimg)[4], const bool (&valid)[4], int nb) {
     static_assert(C0 % 8 == 0 && CW % 8 == 0 && C0 + CW <= 4 * NT, "whole 16-byte pieces of the lane's channels");
     constexpr int CH = 16 / (int)sizeof(T);               // channels per 16-byte piece of T: 8 (bf16) or 4
     constexpr int NP = CW / CH;                           // pieces per row and lane
     constexpr int J0 = C0 / 4, NJ = CW / 4;               // accumulator (channel tile) range
-    nb += C0;
-    int64_t offs[4];
-    uint32_t bimg[4];
-    bool valid[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t m = m_first + 16 * i;
-        valid[i] = m < (uint32_t)gp.M;
-        bimg[i] = 0;
-        int64_t orow = m;
-        if (gp.ostep || temb) {
-            bimg[i] = fdiv(m, gp.div_howo);
-            if (gp.ostep) {
-                const uint32_t rem = m - bimg[i] * (uint32_t)(gp.Ho * gp.Wo);
-                const uint32_t ho = fdiv(rem, gp.div_wo);
-                const uint32_t wo = rem - ho * gp.Wo;
-                orow = ((int64_t)bimg[i] * gp.oH + ho * gp.ostep + gp.oph) * gp.oW + wo * gp.ostep + gp.opw;
-            }
-        }
-        offs[i] = zoff + orow * ldc + nb;
-    }
     if (out_f32) {                                     // fp32 outputs of a bf16 product (attention scores)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -278,6 +259,36 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[NT][4], float* s1, 
             }
         }
     }
+}
+
+// The same for rows m_first + 16*i of the GEMM (with the output scatter of a parity class, if any).
+template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT>
+__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[NT][4], float* s1, float* s2, const Gather& gp,
+                                              const float* temb, const void* res, const void* res2, float alpha,
+                                              int out_f32, void* yout, int N, int ldc, int64_t zoff,
+                                              uint32_t m_first, int nb) {
+    nb += C0;
+    int64_t offs[4];
+    uint32_t bimg[4];
+    bool valid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t m = m_first + 16 * i;
+        valid[i] = m < (uint32_t)gp.M;
+        bimg[i] = 0;
+        int64_t orow = m;
+        if (gp.ostep || temb) {
+            bimg[i] = fdiv(m, gp.div_howo);
+            if (gp.ostep) {
+                const uint32_t rem = m - bimg[i] * (uint32_t)(gp.Ho * gp.Wo);
+                const uint32_t ho = fdiv(rem, gp.div_wo);
+                const uint32_t wo = rem - ho * gp.Wo;
+                orow = ((int64_t)bimg[i] * gp.oH + ho * gp.ostep + gp.oph) * gp.oW + wo * gp.ostep + gp.opw;
+            }
+        }
+        offs[i] = zoff + orow * ldc + nb;
+    }
+    epilogue_rows_at<T, NT, STATS, C0, CW>(acc, s1, s2, temb, res, res2, alpha, out_f32, yout, N, ldc, offs, bimg, valid, nb);
 }
 
 template <typename T, int BN, bool UP>
@@ -1282,6 +1293,192 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
 }
 
 // ------------------------------------------------------------------------------------------
+// 64 -> 64 channels, 3x3, stride 1, pad 1 (bf16): the layers at full resolution, whose implicit GEMM
+// is only 64 columns wide and 576 deep, so that the generic kernels move 1.7 KB from L2 into LDS per
+// output pixel (every input pixel nine times, the filter once per 128-pixel tile).  Here the whole
+// filter (9 taps x 64 x 64 = 72 KB) stays in LDS for the life of the workgroup and a tile's input is
+// fetched ONCE as a halo patch: (PH+2) x (PW+2) pixels x 128 B for PH x PW = 256 output pixels
+// (8 x 32 or 16 x 16), 170 B per output pixel.  A-fragments of tap (r, s) are read from the patch at
+// pixel offset r*(PW+2) + s; rows are 128 B with the 16-byte chunk index XORed with (row & 7), which
+// keeps ds_read_b128 conflict-free at every tap offset.  The next tile's patch is loaded into the
+// second buffer while this tile's 144 MFMAs per wave run: one barrier per tile, none in the K-loop.
+// One workgroup of 8 waves per CU (wave tile 64 pixels x 32 channels), persistent over the tiles.
+struct HaloArgs {
+    int B, H, W;
+    int pw_log2;            // patch width 32 (8 rows) or 16 (16 rows)
+    int tiles_w, tiles_h, ntiles;
+};
+constexpr int kHaloRows = 344;                             // 10 x 34 = 340 (or 18 x 18 = 324) pixels in whole 8-row pieces
+constexpr int kHaloBuf = kHaloRows * 128;
+constexpr int kHaloW = 9 * 64 * 128;                       // resident filter bytes
+constexpr int kHaloLds = kHaloW + 2 * kHaloBuf;
+
+template <bool STATS>
+__global__ void __launch_bounds__(512, 1)
+conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, Epilogue ep,
+                     void* __restrict__ yout) {
+    using T = bf16_t;
+    using Frag = bf16x8_t;
+    constexpr int NT = 2, CPL = 8, N = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wt = smem;
+    unsigned char* halo = smem + kHaloW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int PW = 1 << ha.pw_log2, PH = 256 >> ha.pw_log2, HWd = PW + 2;
+    const int npix = (PH + 2) * HWd;
+
+    // ---- resident filter: tap tile t = 64 rows x 128 B in the row order of the generic kernels' filter
+    // tiles (each lane ends up with 8 consecutive channels); thread copies piece `slot` of row srow
+    {
+        const int srow = tid >> 3, slot = tid & 7;         // 64 rows x 8 pieces
+        const int h = srow >> 5, q = srow & 31;
+        const int n = h * 32 + ((q & 15) >> 2) * CPL + 4 * (q >> 4) + (q & 3);
+        const int chunk = slot ^ (srow & 7);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(w);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            load16_lds(rw, (uint32_t)((n * 9 + t) * 64 + chunk * 8) * 2u, true, wt + t * 8192 + wave_s * 1024);
+    }
+
+    // ---- halo staging: wave `wave` copies pieces wave, wave + 8, ... (8 patch pixels x 128 B each)
+    constexpr int NPC = (kHaloRows / 8 + 7) / 8;            // 6 pieces per wave
+    int h_rc[NPC];                                        // (patch row << 8 | patch column) of this lane's pixel, -1: none
+    int h_chunk[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+        const int hp = (wave + 8 * j) * 8 + (lane >> 3);
+        const int hr = hp / HWd, hc = hp - hr * HWd;
+        h_rc[j] = hp < npix ? (hr << 8) | hc : -1;
+        h_chunk[j] = ((lane & 7) ^ (hp & 7)) * 8;
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x);
+    auto stage = [&](int tile, int buf) {
+        const int tx = tile % ha.tiles_w;
+        const int ty = (tile / ha.tiles_w) % ha.tiles_h;
+        const int b = tile / (ha.tiles_w * ha.tiles_h);
+        const int h0 = ty * PH - 1, w0 = tx * PW - 1;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) {
+            if ((wave_s + 8 * j) * 8 >= kHaloRows) continue;               // uniform: no such piece
+            const int hi = h0 + (h_rc[j] >> 8), wi = w0 + (h_rc[j] & 255);
+            const bool ok = h_rc[j] >= 0 && (unsigned)hi < (unsigned)ha.H && (unsigned)wi < (unsigned)ha.W;
+            const int off = ((b * ha.H + hi) * ha.W + wi) * 64 + h_chunk[j];
+            load16_lds(rx, (uint32_t)off * 2u, ok, halo + buf * kHaloBuf + (wave_s + 8 * j) * 1024);
+        }
+    };
+
+    // ---- fragments
+    const int frow = lane & 15, fgrp = lane >> 4;
+    int hp0[4];                                           // patch pixel of this lane in pixel tile i, as a halo row of tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wm * 64 + i * 16 + frow;
+        hp0[i] = (q >> ha.pw_log2) * HWd + (q & (PW - 1));
+    }
+    const unsigned char* sb = wt + (wn * 32 + frow) * 128;
+    const int bsw = frow & 7;
+    f32x4_t acc[NT][4];
+    const int nb = wn * 32 + fgrp * CPL;
+    float s1[STATS ? CPL : 1], s2[STATS ? CPL : 1];
+#pragma unroll
+    for (int e = 0; e < (STATS ? CPL : 1); ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (ep.bias) {
+                const float4 t4 = *reinterpret_cast<const float4*>(ep.bias + nb + 4 * j);
+                bv = f32x4_t{t4.x, t4.y, t4.z, t4.w};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = bv;
+        }
+    };
+
+    const int nblk = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, nblk);
+    int buf = 0;
+    if (tile < ha.ntiles) stage(tile, 0);
+    init_acc();
+    for (; tile < ha.ntiles; tile += nblk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // this tile's patch (and the filter) is in LDS; every wave is past the previous tile
+        if (tile + nblk < ha.ntiles) stage(tile + nblk, buf ^ 1);
+        const unsigned char* sa = halo + buf * kHaloBuf;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = (t / 3) * HWd + (t % 3);
+            int arow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) arow[i] = hp0[i] + toff;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag a[4], b[NT];
+                const int c = ks * 4 + fgrp;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = *reinterpret_cast<const Frag*>(sa + arow[i] * 128 + ((c ^ (arow[i] & 7)) << 4));
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    b[j] = *reinterpret_cast<const Frag*>(sb + t * 8192 + j * 16 * 128 + ((c ^ bsw) << 4));
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+            }
+        }
+        // ---- epilogue of this tile
+        {
+            const int tx = tile % ha.tiles_w;
+            const int ty = (tile / ha.tiles_w) % ha.tiles_h;
+            const int b = tile / (ha.tiles_w * ha.tiles_h);
+            int64_t offs[4];
+            uint32_t bimg[4];
+            bool valid[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = wm * 64 + i * 16 + frow;
+                const int h = ty * PH + (q >> ha.pw_log2), wq = tx * PW + (q & (PW - 1));
+                valid[i] = h < ha.H && wq < ha.W;
+                bimg[i] = (uint32_t)b;
+                offs[i] = (((int64_t)b * ha.H + h) * ha.W + wq) * N + nb;
+            }
+            // (a lane's first row is its top-left one: if that is outside the image, so are the others)
+            epilogue_rows_at<T, NT, STATS>(acc, s1, s2, ep.temb, ep.res, ep.res2, ep.alpha, 0, yout, N, N, offs, bimg, valid, nb);
+        }
+        init_acc();
+        buf ^= 1;
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s1[e] += __shfl_xor(s1[e], o, 64);
+                s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+        }
+        __syncthreads();                                  // every wave is done with the patches
+        float* red = reinterpret_cast<float*>(halo);      // [wm][64 channels][2]
+        if (frow == 0) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                red[(wm * N + nb + e) * 2 + 0] = s1[e];
+                red[(wm * N + nb + e) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < N * 2; idx += 512)
+            ep.stats[((int64_t)blockIdx.x * N) * 2 + idx] =
+                (red[idx] + red[N * 2 + idx]) + (red[2 * N * 2 + idx] + red[3 * N * 2 + idx]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Weight gradient: dW[n][f] += sum over a slice of pixels m of dY[m][n] * Xg[m][f].
 // Both operands are "reduction-major" in memory (channel innermost), so their MFMA fragments are
 // read with the transposing LDS read ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (fp32).
@@ -1856,10 +2053,56 @@ static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ld
     return 0;
 }
 
+// Resident-filter halo kernel: plain 3x3 / stride 1 / pad 1 over 64 -> 64 channels in bf16 with enough
+// 256-pixel patches to fill the chip (VAMD_C64_HALO=0 switches it off, VAMD_C64_HALO_MIN=1 forces it
+// for every such shape).  The patch is 8 x 32 or 16 x 16 pixels, whichever covers the image with fewer.
+static bool c64_halo_shape(int H, int W, int64_t M, int* pw_log2, int* tiles_w, int* tiles_h, int* ntiles) {
+    static const int on = [] { const char* e = getenv("VAMD_C64_HALO"); return e ? atoi(e) : 1; }();
+    static const int min_tiles = [] { const char* e = getenv("VAMD_C64_HALO_MIN"); return e ? atoi(e) : 512; }();
+    if (!on || nt_classic() || H <= 0 || W <= 0 || M % ((int64_t)H * W) != 0 || M * 128 >= 0x7FFFFFF0ll) return false;
+    const int B = (int)(M / ((int64_t)H * W));
+    const int n32 = ((H + 7) / 8) * ((W + 31) / 32), n16 = ((H + 15) / 16) * ((W + 15) / 16);
+    const bool wide = n32 <= n16;
+    *pw_log2 = wide ? 5 : 4;
+    *tiles_w = wide ? (W + 31) / 32 : (W + 15) / 16;
+    *tiles_h = wide ? (H + 7) / 8 : (H + 15) / 16;
+    *ntiles = B * (wide ? n32 : n16);
+    return *ntiles >= min_tiles;
+}
+static bool c64_halo_gather(const Gather& gp, int N, int ldw, int ldc, const Epilogue& ep, int batch) {
+    return gp.Cin == 64 && gp.ldx == 64 && N == 64 && ldw == 576 && ldc == 64 && batch == 1 && gp.kr == 3 && gp.ks == 3 &&
+           gp.k == 3 && gp.stride == 1 && gp.pad == 1 && gp.padw == 1 && !gp.shift && !gp.ostep && gp.wr0 == 0 && gp.ws0 == 0 &&
+           gp.wstep == 1 && gp.wk == 3 && gp.Cin2 == 0 && gp.Hin == gp.He && gp.Win == gp.We && gp.Ho == gp.Hin && gp.Wo == gp.Win &&
+           !ep.out_f32 && ep.alpha == 1.0f && gp.Ktot == 576;
+}
+
+static int launch_c64_halo(const Gather& gp, const bf16_t* x, const bf16_t* w, const Epilogue& ep, void* y,
+                           int pw_log2, int tiles_w, int tiles_h, int ntiles, hipStream_t st) {
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds_limit(conv_c64_halo_kernel<false>, kHaloLds, "conv_c64_halo");
+        if (!rc) rc = set_lds_limit(conv_c64_halo_kernel<true>, kHaloLds, "conv_c64_halo");
+        if (rc) return rc;
+        configured = true;
+    }
+    HaloArgs ha{(int)(gp.M / ((int64_t)gp.Hin * gp.Win)), gp.Hin, gp.Win, pw_log2, tiles_w, tiles_h, ntiles};
+    const int blocks = ntiles < 256 ? ntiles : 256;
+    TimedLaunch timed(TIMED_NT, take_flops(2.0 * gp.M * 64 * 576), st);
+    if (ep.stats) hipLaunchKernelGGL(conv_c64_halo_kernel<true>, dim3(blocks), dim3(512), kHaloLds, st, ha, x, w, ep, y);
+    else hipLaunchKernelGGL(conv_c64_halo_kernel<false>, dim3(blocks), dim3(512), kHaloLds, st, ha, x, w, ep, y);
+    VAMD_LAUNCH_OK("conv_c64_halo");
+    return 0;
+}
+
 template <typename T>
 static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep,
                   void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st,
                   const ClassSet* classes = nullptr) {
+    if constexpr (sizeof(T) == 2) {
+        int pwl, tw, th, nt;
+        if (!classes && c64_halo_gather(gp, N, ldw, ldc, ep, batch) && c64_halo_shape(gp.Hin, gp.Win, gp.M, &pwl, &tw, &th, &nt))
+            return launch_c64_halo(gp, (const bf16_t*)x, (const bf16_t*)w, ep, y, pwl, tw, th, nt, st);
+    }
     if (classes) {                                        // class sets: stride-1 gathers without upsampling
         if (N <= 64) return launch_nt<T, 64, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
         return launch_nt<T, 128, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
@@ -1895,6 +2138,10 @@ bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype) {
 int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype) {
     const int m_tiles = (int)((g.M + kBM - 1) / kBM);
     if (nt_classic()) return m_tiles;
+    if (dtype == VAMD_BF16 && g.Cin == 64 && g.Cout == 64 && g.k == 3 && g.stride == 1 && g.pad == 1 && !g.up) {
+        int pwl, tw, th, nt;                              // as run_nt picks the resident-filter kernel
+        if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return nt < 256 ? nt : 256;
+    }
     if (dtype == VAMD_BF16 && nt_wide256(g.Cout, g.M, 1, 2, g.k * g.k * g.Cin, g.up != 0)) return ntp_row_groups((int)((g.M + 255) / 256), g.Cout / 256, 1);
     const int BN = g.Cout <= 64 ? 64 : 128;               // as run_nt picks
     const int n_tiles = (g.Cout + BN - 1) / BN;
@@ -1917,6 +2164,10 @@ bool conv_fwd_short_mfma_supported(const ConvGeom& g, int dtype, int Cin2) {
     const int kstep = dtype == VAMD_BF16 ? 64 : 32;
     if (nt_classic() || g.up || g.stride != 1 || Cin2 <= 0 || Cin2 % kstep != 0 || g.Cin % kstep != 0) return false;
     if ((int64_t)g.M * Cin2 >= (1ll << 30)) return false;      // 32-bit byte offsets into x2
+    if (dtype == VAMD_BF16 && g.Cin == 64 && g.Cout == 64 && g.k == 3 && g.pad == 1) {
+        int pwl, tw, th, nt;                              // the resident-filter kernel serves the plain conv: keep the two launches
+        if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return false;
+    }
     return nt_shape_ok(g.Cin, g.Cout, g.M, dtype);
 }
 
