@@ -82,6 +82,8 @@ CONV_CASES = [
     (2, 16, 32, 64, 64, 3, 1, 0),
     (2, 19, 37, 64, 64, 3, 1, 0),      # ragged 8 x 32 patches of the resident-filter kernel (when forced)
     (3, 33, 20, 64, 64, 3, 1, 0),      # ragged 16 x 16 patches
+    (2, 20, 24, 64, 128, 3, 1, 0),     # two column tiles of the resident-filter kernel (forward)
+    (2, 12, 20, 128, 64, 3, 1, 0),     # ... (input gradient)
     (1, 24, 48, 128, 128, 3, 1, 0),
     (1, 8, 16, 64, 64, 3, 1, 1),
     (1, 32, 64, 64, 128, 3, 2, 0),

@@ -1293,8 +1293,8 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
 }
 
 // ------------------------------------------------------------------------------------------
-// 64 -> 64 channels, 3x3, stride 1, pad 1 (bf16): the layers at full resolution, whose implicit GEMM
-// is only 64 columns wide and 576 deep, so that the generic kernels move 1.7 KB from L2 into LDS per
+// 64 input channels, 3x3, stride 1, pad 1 (bf16): the layers at full resolution, whose implicit GEMM
+// is only 576 deep (and 64 or 128 columns wide), so that the generic kernels move 1.7 KB from L2 into LDS per
 // output pixel (every input pixel nine times, the filter once per 128-pixel tile).  Here the whole
 // filter (9 taps x 64 x 64 = 72 KB) stays in LDS for the life of the workgroup and a tile's input is
 // fetched ONCE as a halo patch: (PH+2) x (PW+2) pixels x 128 B for PH x PW = 256 output pixels
@@ -1307,6 +1307,7 @@ struct HaloArgs {
     int B, H, W;
     int pw_log2;            // patch width 32 (8 rows) or 16 (16 rows)
     int tiles_w, tiles_h, ntiles;
+    int N, n_tiles;         // output channels (a multiple of 64) and column tiles of 64: a workgroup keeps one column tile's filter
 };
 constexpr int kHaloRows = 344;                             // 10 x 34 = 340 (or 18 x 18 = 324) pixels in whole 8-row pieces
 constexpr int kHaloBuf = kHaloRows * 128;
@@ -1319,7 +1320,8 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
                      void* __restrict__ yout) {
     using T = bf16_t;
     using Frag = bf16x8_t;
-    constexpr int NT = 2, CPL = 8, N = 64;
+    constexpr int NT = 2, CPL = 8;
+    const int N = ha.N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wt = smem;
     unsigned char* halo = smem + kHaloW;
@@ -1328,6 +1330,8 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
     const int wm = wave >> 1, wn = wave & 1;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int PW = 1 << ha.pw_log2, PH = 256 >> ha.pw_log2, HWd = PW + 2;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (bid % ha.n_tiles) * 64;                // this workgroup's column tile, fixed
     const int npix = (PH + 2) * HWd;
 
     // ---- resident filter: tap tile t = 64 rows x 128 B in the row order of the generic kernels' filter
@@ -1335,7 +1339,7 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
     {
         const int srow = tid >> 3, slot = tid & 7;         // 64 rows x 8 pieces
         const int h = srow >> 5, q = srow & 31;
-        const int n = h * 32 + ((q & 15) >> 2) * CPL + 4 * (q >> 4) + (q & 3);
+        const int n = n0 + h * 32 + ((q & 15) >> 2) * CPL + 4 * (q >> 4) + (q & 3);
         const int chunk = slot ^ (srow & 7);
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(w);
 #pragma unroll
@@ -1381,7 +1385,7 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
     const unsigned char* sb = wt + (wn * 32 + frow) * 128;
     const int bsw = frow & 7;
     f32x4_t acc[NT][4];
-    const int nb = wn * 32 + fgrp * CPL;
+    const int nb = n0 + wn * 32 + fgrp * CPL;
     float s1[STATS ? CPL : 1], s2[STATS ? CPL : 1];
 #pragma unroll
     for (int e = 0; e < (STATS ? CPL : 1); ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -1398,8 +1402,8 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
         }
     };
 
-    const int nblk = gridDim.x;
-    int tile = xcd_remap(blockIdx.x, nblk);
+    const int nblk = gridDim.x / ha.n_tiles;             // tiles advance by this
+    int tile = bid / ha.n_tiles;
     int buf = 0;
     if (tile < ha.ntiles) stage(tile, 0);
     init_acc();
@@ -1463,18 +1467,18 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
             }
         }
         __syncthreads();                                  // every wave is done with the patches
-        float* red = reinterpret_cast<float*>(halo);      // [wm][64 channels][2]
+        float* red = reinterpret_cast<float*>(halo);      // [wm][64 channels of the column tile][2]
         if (frow == 0) {
 #pragma unroll
             for (int e = 0; e < CPL; ++e) {
-                red[(wm * N + nb + e) * 2 + 0] = s1[e];
-                red[(wm * N + nb + e) * 2 + 1] = s2[e];
+                red[(wm * 64 + nb - n0 + e) * 2 + 0] = s1[e];
+                red[(wm * 64 + nb - n0 + e) * 2 + 1] = s2[e];
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < N * 2; idx += 512)
-            ep.stats[((int64_t)blockIdx.x * N) * 2 + idx] =
-                (red[idx] + red[N * 2 + idx]) + (red[2 * N * 2 + idx] + red[3 * N * 2 + idx]);
+        for (int idx = tid; idx < 64 * 2; idx += 512)
+            ep.stats[((int64_t)(bid / ha.n_tiles) * N + n0) * 2 + idx] =
+                (red[idx] + red[64 * 2 + idx]) + (red[2 * 64 * 2 + idx] + red[3 * 64 * 2 + idx]);
     }
 }
 
@@ -2070,13 +2074,18 @@ static bool c64_halo_shape(int H, int W, int64_t M, int* pw_log2, int* tiles_w, 
     return *ntiles >= min_tiles;
 }
 static bool c64_halo_gather(const Gather& gp, int N, int ldw, int ldc, const Epilogue& ep, int batch) {
-    return gp.Cin == 64 && gp.ldx == 64 && N == 64 && ldw == 576 && ldc == 64 && batch == 1 && gp.kr == 3 && gp.ks == 3 &&
+    return gp.Cin == 64 && gp.ldx == 64 && (N == 64 || N == 128) && ldw == 576 && ldc == N && batch == 1 && gp.kr == 3 && gp.ks == 3 &&
            gp.k == 3 && gp.stride == 1 && gp.pad == 1 && gp.padw == 1 && !gp.shift && !gp.ostep && gp.wr0 == 0 && gp.ws0 == 0 &&
            gp.wstep == 1 && gp.wk == 3 && gp.Cin2 == 0 && gp.Hin == gp.He && gp.Win == gp.We && gp.Ho == gp.Hin && gp.Wo == gp.Win &&
            !ep.out_f32 && ep.alpha == 1.0f && gp.Ktot == 576;
 }
 
-static int launch_c64_halo(const Gather& gp, const bf16_t* x, const bf16_t* w, const Epilogue& ep, void* y,
+static int c64_halo_blocks(int ntiles, int n_tiles) {
+    const int per_column = 256 / n_tiles;
+    return (ntiles < per_column ? ntiles : per_column) * n_tiles;
+}
+
+static int launch_c64_halo(const Gather& gp, const bf16_t* x, const bf16_t* w, int N, const Epilogue& ep, void* y,
                            int pw_log2, int tiles_w, int tiles_h, int ntiles, hipStream_t st) {
     static bool configured = false;
     if (!configured) {
@@ -2085,9 +2094,9 @@ static int launch_c64_halo(const Gather& gp, const bf16_t* x, const bf16_t* w, c
         if (rc) return rc;
         configured = true;
     }
-    HaloArgs ha{(int)(gp.M / ((int64_t)gp.Hin * gp.Win)), gp.Hin, gp.Win, pw_log2, tiles_w, tiles_h, ntiles};
-    const int blocks = ntiles < 256 ? ntiles : 256;
-    TimedLaunch timed(TIMED_NT, take_flops(2.0 * gp.M * 64 * 576), st);
+    HaloArgs ha{(int)(gp.M / ((int64_t)gp.Hin * gp.Win)), gp.Hin, gp.Win, pw_log2, tiles_w, tiles_h, ntiles, N, N / 64};
+    const int blocks = c64_halo_blocks(ntiles, N / 64);
+    TimedLaunch timed(TIMED_NT, take_flops(2.0 * gp.M * N * 576), st);
     if (ep.stats) hipLaunchKernelGGL(conv_c64_halo_kernel<true>, dim3(blocks), dim3(512), kHaloLds, st, ha, x, w, ep, y);
     else hipLaunchKernelGGL(conv_c64_halo_kernel<false>, dim3(blocks), dim3(512), kHaloLds, st, ha, x, w, ep, y);
     VAMD_LAUNCH_OK("conv_c64_halo");
@@ -2101,7 +2110,7 @@ static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw
     if constexpr (sizeof(T) == 2) {
         int pwl, tw, th, nt;
         if (!classes && c64_halo_gather(gp, N, ldw, ldc, ep, batch) && c64_halo_shape(gp.Hin, gp.Win, gp.M, &pwl, &tw, &th, &nt))
-            return launch_c64_halo(gp, (const bf16_t*)x, (const bf16_t*)w, ep, y, pwl, tw, th, nt, st);
+            return launch_c64_halo(gp, (const bf16_t*)x, (const bf16_t*)w, N, ep, y, pwl, tw, th, nt, st);
     }
     if (classes) {                                        // class sets: stride-1 gathers without upsampling
         if (N <= 64) return launch_nt<T, 64, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
@@ -2138,9 +2147,9 @@ bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype) {
 int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype) {
     const int m_tiles = (int)((g.M + kBM - 1) / kBM);
     if (nt_classic()) return m_tiles;
-    if (dtype == VAMD_BF16 && g.Cin == 64 && g.Cout == 64 && g.k == 3 && g.stride == 1 && g.pad == 1 && !g.up) {
+    if (dtype == VAMD_BF16 && g.Cin == 64 && (g.Cout == 64 || g.Cout == 128) && g.k == 3 && g.stride == 1 && g.pad == 1 && !g.up) {
         int pwl, tw, th, nt;                              // as run_nt picks the resident-filter kernel
-        if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return nt < 256 ? nt : 256;
+        if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return c64_halo_blocks(nt, g.Cout / 64) / (g.Cout / 64);
     }
     if (dtype == VAMD_BF16 && nt_wide256(g.Cout, g.M, 1, 2, g.k * g.k * g.Cin, g.up != 0)) return ntp_row_groups((int)((g.M + 255) / 256), g.Cout / 256, 1);
     const int BN = g.Cout <= 64 ? 64 : 128;               // as run_nt picks
@@ -2164,7 +2173,7 @@ bool conv_fwd_short_mfma_supported(const ConvGeom& g, int dtype, int Cin2) {
     const int kstep = dtype == VAMD_BF16 ? 64 : 32;
     if (nt_classic() || g.up || g.stride != 1 || Cin2 <= 0 || Cin2 % kstep != 0 || g.Cin % kstep != 0) return false;
     if ((int64_t)g.M * Cin2 >= (1ll << 30)) return false;      // 32-bit byte offsets into x2
-    if (dtype == VAMD_BF16 && g.Cin == 64 && g.Cout == 64 && g.k == 3 && g.pad == 1) {
+    if (dtype == VAMD_BF16 && g.Cin == 64 && (g.Cout == 64 || g.Cout == 128) && g.k == 3 && g.pad == 1) {
         int pwl, tw, th, nt;                              // the resident-filter kernel serves the plain conv: keep the two launches
         if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return false;
     }
