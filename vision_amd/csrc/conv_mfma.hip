@@ -1411,6 +1411,38 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // this tile's patch (and the filter) is in LDS; every wave is past the previous tile
         if (tile + nblk < ha.ntiles) stage(tile + nblk, buf ^ 1);
+        // ---- this tile's rows, and its epilogue operands: loaded now, used after the 144 MFMAs
+        int64_t offs[4];
+        bool valid[4];
+        int img;
+        {
+            const int tx = tile % ha.tiles_w;
+            const int ty = (tile / ha.tiles_w) % ha.tiles_h;
+            img = tile / (ha.tiles_w * ha.tiles_h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = wm * 64 + i * 16 + frow;
+                const int h = ty * PH + (q >> ha.pw_log2), wq = tx * PW + (q & (PW - 1));
+                valid[i] = h < ha.H && wq < ha.W;
+                offs[i] = (((int64_t)img * ha.H + h) * ha.W + wq) * N + nb;
+            }
+        }
+        float tv[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) tv[e] = 0.f;
+        if (ep.temb) {
+            const float4 t0 = *reinterpret_cast<const float4*>(ep.temb + (int64_t)img * N + nb);
+            const float4 t1 = *reinterpret_cast<const float4*>(ep.temb + (int64_t)img * N + nb + 4);
+            tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
+        }
+        const T* r1 = reinterpret_cast<const T*>(ep.res ? ep.res : ep.res2);
+        const T* r2 = reinterpret_cast<const T*>(ep.res ? ep.res2 : nullptr);
+        Vec16<T> rv[4];
+        if (r1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (valid[i]) rv[i] = *reinterpret_cast<const Vec16<T>*>(r1 + offs[i]);
+        }
         const unsigned char* sa = halo + buf * kHaloBuf;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -1435,24 +1467,34 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
                         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
             }
         }
-        // ---- epilogue of this tile
-        {
-            const int tx = tile % ha.tiles_w;
-            const int ty = (tile / ha.tiles_w) % ha.tiles_h;
-            const int b = tile / (ha.tiles_w * ha.tiles_h);
-            int64_t offs[4];
-            uint32_t bimg[4];
-            bool valid[4];
+        // ---- epilogue of this tile: y = acc + temb + res + res2 (in this order), rounded, stored, summed
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = wm * 64 + i * 16 + frow;
-                const int h = ty * PH + (q >> ha.pw_log2), wq = tx * PW + (q & (PW - 1));
-                valid[i] = h < ha.H && wq < ha.W;
-                bimg[i] = (uint32_t)b;
-                offs[i] = (((int64_t)b * ha.H + h) * ha.W + wq) * N + nb;
+        for (int i = 0; i < 4; ++i) {
+            if (!valid[i]) continue;
+            float v[CPL];
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) v[e] = acc[e >> 2][i][e & 3] + tv[e];
+            if (r1) {
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) v[e] += to_f(rv[i].v[e]);
             }
-            // (a lane's first row is its top-left one: if that is outside the image, so are the others)
-            epilogue_rows_at<T, NT, STATS>(acc, s1, s2, ep.temb, ep.res, ep.res2, ep.alpha, 0, yout, N, N, offs, bimg, valid, nb);
+            if (r2) {
+                const Vec16<T> q2 = *reinterpret_cast<const Vec16<T>*>(r2 + offs[i]);
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) v[e] += to_f(q2.v[e]);
+            }
+            Vec16<T> ov;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) ov.v[e] = from_f<T>(v[e]);
+            *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + offs[i]) = ov;
+            if constexpr (STATS) {                        // statistics of the rounded values a later pass would read
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) {
+                    const float q = to_f(ov.v[e]);
+                    s1[e] += q;
+                    s2[e] = fmaf(q, q, s2[e]);
+                }
+            }
         }
         init_acc();
         buf ^= 1;
