@@ -156,3 +156,20 @@ def test_shard_rows_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_grad_reducer_bucket_layout():
+    """Buckets tile the arena from the tail, and the one that is complete only when backward ends
+    (it starts at offset 0) is cut down to the first layers within head_bytes."""
+    flat = torch.zeros(1000)
+    bounds = [0, 10, 50, 100, 400, 700]
+    for bucket_bytes, head_bytes in [(1200, 250), (1200, 20), (4000, 250), (4, 4), (1 << 20, 1 << 20)]:
+        r = GradReducer(flat, bounds, bucket_bytes=bucket_bytes, head_bytes=head_bytes)
+        assert r.buckets[0][1] == 1000 and r.buckets[-1][0] == 0
+        for (lo, hi), (lo2, hi2) in zip(r.buckets, r.buckets[1:]):
+            assert lo < hi and hi2 == lo                     # contiguous, tail first
+        assert all(lo in bounds for lo, _ in r.buckets)      # cut at layer boundaries only
+    r = GradReducer(flat, bounds, bucket_bytes=1200, head_bytes=250)
+    assert r.buckets[-1] == (0, 50) and r.buckets[-2] == (50, 100)
+    r = GradReducer(flat, bounds, bucket_bytes=1200, head_bytes=20)       # no boundary within the head: unchanged
+    assert r.buckets[-1] == (0, 100)

@@ -61,7 +61,8 @@ class GradReducer:
     become final from the last boundary backwards.  GPU tensors go to nccl/RCCL directly; with
     any other backend (gloo) they are staged through host memory, CPU tensors are used as they are."""
 
-    def __init__(self, flat_grads: torch.Tensor, boundaries: List[int], group=None, bucket_bytes=25 << 20):
+    def __init__(self, flat_grads: torch.Tensor, boundaries: List[int], group=None, bucket_bytes=25 << 20,
+                 head_bytes=4 << 20):
         self.flat, self.group = flat_grads, group
         self.rank, self.world = world_info(group)
         self.total = flat_grads.numel()
@@ -72,6 +73,15 @@ class GradReducer:
             if hi - b >= min_elems or b == 0:
                 cut.append((b, hi))
                 hi = b
+        # The bucket that starts at 0 is complete only when backward ends, so its all-reduce overlaps with
+        # nothing: keep it small (the first layers' parameters are few) by splitting it at the highest
+        # layer boundary within head_bytes; the part above goes out while the first layers' backward runs.
+        head_elems = max(1, head_bytes // flat_grads.element_size())
+        if cut and cut[-1][0] == 0 and cut[-1][1] > head_elems:
+            inner = [b for b in bset if 0 < b <= head_elems and b < cut[-1][1]]
+            if inner:
+                lo, hi = cut.pop()
+                cut += [(inner[-1], hi), (lo, inner[-1])]
         self.buckets = cut                    # tail first, last one starts at 0
         self._next = 0
         self._pending = []
