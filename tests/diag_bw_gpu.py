@@ -1,3 +1,5 @@
+"""Plain fill / copy / reduce of a 411 MB bf16 tensor (the 64-channel activation at 224 x 224, batch 64) with torch's
+own kernels: what the card gives a streaming kernel, for judging the HBM-bound kernels (not a pytest file)."""
 import torch, time
 n = 64*224*224*64
 a = torch.empty(n, dtype=torch.bfloat16, device="cuda"); b = torch.empty_like(a)
