@@ -93,6 +93,7 @@ CONV_CASES = [
     (2, 12, 12, 64, 64, 3, 2, 0),
     (2, 7, 9, 32, 32, 3, 2, 0),
     (2, 6, 5, 64, 64, 3, 1, 1),
+    (1, 10, 37, 64, 128, 3, 1, 1),     # upsampling forward on the resident-filter kernel (when forced): two column tiles x four classes
     (2, 9, 9, 64, 128, 1, 1, 0),
     (2, 16, 16, 3, 32, 3, 1, 0),
     (2, 16, 16, 32, 3, 3, 1, 0),

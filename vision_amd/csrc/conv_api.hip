@@ -176,7 +176,7 @@ int vamd_conv2d_fwd_up4_supported(const vamd_conv_desc* d) {
 int vamd_conv2d_fwd_up4_stats_parts(const vamd_conv_desc* d) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_fwd_up4_stats_parts")) return 0;
-    return conv_fwd_up4_mfma_supported(g, d->dtype) ? conv_fwd_up4_mfma_stats_parts(g) : 0;
+    return conv_fwd_up4_mfma_supported(g, d->dtype) ? conv_fwd_up4_mfma_stats_parts(g, d->dtype) : 0;
 }
 
 int vamd_conv2d_fwd_up4(const vamd_conv_desc* d, const void* x, const void* w_up4, const float* bias,

@@ -1308,30 +1308,36 @@ struct HaloArgs {
     int pw_log2;            // patch width 32 (8 rows) or 16 (16 rows)
     int tiles_w, tiles_h, ntiles;
     int N, n_tiles;         // output channels (a multiple of 64) and column tiles of 64: a workgroup keeps one column tile's filter
+    // Parity classes of an upsampling forward (ncls = 4, ostep = 2): class (ph, pw) is a KR x KS = 2 x 2 convolution over the
+    // stored input whose taps start at patch offset (ph, pw); pixel (i, j) is written to (2i + ph, 2j + pw) of a 2H x 2W
+    // image; its filter starts w_cls elements after the previous class's.  A workgroup keeps one class's filter.
+    int ncls, ostep;
+    int64_t w_cls;
 };
 constexpr int kHaloRows = 344;                             // 10 x 34 = 340 (or 18 x 18 = 324) pixels in whole 8-row pieces
 constexpr int kHaloBuf = kHaloRows * 128;
-constexpr int kHaloW = 9 * 64 * 128;                       // resident filter bytes
-constexpr int kHaloLds = kHaloW + 2 * kHaloBuf;
+constexpr int halo_lds_bytes(int ntaps) { return ntaps * 64 * 128 + 2 * kHaloBuf; }   // resident filter + two patches
 
-template <bool STATS>
+template <bool STATS, int KR, int KS>
 __global__ void __launch_bounds__(512, 1)
 conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, Epilogue ep,
                      void* __restrict__ yout) {
     using T = bf16_t;
     using Frag = bf16x8_t;
-    constexpr int NT = 2, CPL = 8;
+    constexpr int NT = 2, CPL = 8, NTAPS = KR * KS;
     const int N = ha.N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wt = smem;
-    unsigned char* halo = smem + kHaloW;
+    unsigned char* halo = smem + NTAPS * 8192;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int PW = 1 << ha.pw_log2, PH = 256 >> ha.pw_log2, HWd = PW + 2;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = (bid % ha.n_tiles) * 64;                // this workgroup's column tile, fixed
+    const int combos = ha.n_tiles * ha.ncls;
+    const int n0 = (bid % ha.n_tiles) * 64;                // this workgroup's column tile and class, fixed
+    const int cls = (bid % combos) / ha.n_tiles, ph = cls >> 1, pw = cls & 1;
     const int npix = (PH + 2) * HWd;
 
     // ---- resident filter: tap tile t = 64 rows x 128 B in the row order of the generic kernels' filter
@@ -1341,10 +1347,10 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
         const int h = srow >> 5, q = srow & 31;
         const int n = n0 + h * 32 + ((q & 15) >> 2) * CPL + 4 * (q >> 4) + (q & 3);
         const int chunk = slot ^ (srow & 7);
-        const __amdgpu_buffer_rsrc_t rw = make_rsrc(w);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(w + cls * ha.w_cls);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-            load16_lds(rw, (uint32_t)((n * 9 + t) * 64 + chunk * 8) * 2u, true, wt + t * 8192 + wave_s * 1024);
+        for (int t = 0; t < NTAPS; ++t)
+            load16_lds(rw, (uint32_t)((n * NTAPS + t) * 64 + chunk * 8) * 2u, true, wt + t * 8192 + wave_s * 1024);
     }
 
     // ---- halo staging: wave `wave` copies pieces wave, wave + 8, ... (8 patch pixels x 128 B each)
@@ -1402,8 +1408,8 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
         }
     };
 
-    const int nblk = gridDim.x / ha.n_tiles;             // tiles advance by this
-    int tile = bid / ha.n_tiles;
+    const int nblk = gridDim.x / combos;                 // tiles advance by this
+    int tile = bid / combos;
     int buf = 0;
     if (tile < ha.ntiles) stage(tile, 0);
     init_acc();
@@ -1424,7 +1430,8 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
                 const int q = wm * 64 + i * 16 + frow;
                 const int h = ty * PH + (q >> ha.pw_log2), wq = tx * PW + (q & (PW - 1));
                 valid[i] = h < ha.H && wq < ha.W;
-                offs[i] = (((int64_t)img * ha.H + h) * ha.W + wq) * N + nb;
+                offs[i] = ha.ostep ? (((int64_t)img * 2 * ha.H + 2 * h + ph) * 2 * ha.W + 2 * wq + pw) * N + nb
+                                   : (((int64_t)img * ha.H + h) * ha.W + wq) * N + nb;
             }
         }
         float tv[CPL];
@@ -1445,8 +1452,8 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
         }
         const unsigned char* sa = halo + buf * kHaloBuf;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int toff = (t / 3) * HWd + (t % 3);
+        for (int t = 0; t < NTAPS; ++t) {
+            const int toff = (ph + t / KS) * HWd + pw + (t % KS);
             int arow[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) arow[i] = hp0[i] + toff;
@@ -2122,25 +2129,26 @@ static bool c64_halo_gather(const Gather& gp, int N, int ldw, int ldc, const Epi
            !ep.out_f32 && ep.alpha == 1.0f && gp.Ktot == 576;
 }
 
-static int c64_halo_blocks(int ntiles, int n_tiles) {
-    const int per_column = 256 / n_tiles;
-    return (ntiles < per_column ? ntiles : per_column) * n_tiles;
+static int c64_halo_blocks(int ntiles, int combos) {       // combos: column tiles x classes, each with its own block range
+    const int per_combo = 256 / combos;
+    return (ntiles < per_combo ? ntiles : per_combo) * combos;
 }
 
-static int launch_c64_halo(const Gather& gp, const bf16_t* x, const bf16_t* w, int N, const Epilogue& ep, void* y,
-                           int pw_log2, int tiles_w, int tiles_h, int ntiles, hipStream_t st) {
+template <int KR, int KS>
+static int launch_c64_halo(const HaloArgs& ha, const bf16_t* x, const bf16_t* w, const Epilogue& ep, void* y, double flops,
+                           hipStream_t st) {
+    constexpr int LDS = halo_lds_bytes(KR * KS);
     static bool configured = false;
     if (!configured) {
-        int rc = set_lds_limit(conv_c64_halo_kernel<false>, kHaloLds, "conv_c64_halo");
-        if (!rc) rc = set_lds_limit(conv_c64_halo_kernel<true>, kHaloLds, "conv_c64_halo");
+        int rc = set_lds_limit(conv_c64_halo_kernel<false, KR, KS>, LDS, "conv_c64_halo");
+        if (!rc) rc = set_lds_limit(conv_c64_halo_kernel<true, KR, KS>, LDS, "conv_c64_halo");
         if (rc) return rc;
         configured = true;
     }
-    HaloArgs ha{(int)(gp.M / ((int64_t)gp.Hin * gp.Win)), gp.Hin, gp.Win, pw_log2, tiles_w, tiles_h, ntiles, N, N / 64};
-    const int blocks = c64_halo_blocks(ntiles, N / 64);
-    TimedLaunch timed(TIMED_NT, take_flops(2.0 * gp.M * N * 576), st);
-    if (ep.stats) hipLaunchKernelGGL(conv_c64_halo_kernel<true>, dim3(blocks), dim3(512), kHaloLds, st, ha, x, w, ep, y);
-    else hipLaunchKernelGGL(conv_c64_halo_kernel<false>, dim3(blocks), dim3(512), kHaloLds, st, ha, x, w, ep, y);
+    const int blocks = c64_halo_blocks(ha.ntiles, ha.n_tiles * ha.ncls);
+    TimedLaunch timed(TIMED_NT, take_flops(flops), st);
+    if (ep.stats) hipLaunchKernelGGL((conv_c64_halo_kernel<true, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
+    else hipLaunchKernelGGL((conv_c64_halo_kernel<false, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
     VAMD_LAUNCH_OK("conv_c64_halo");
     return 0;
 }
@@ -2152,7 +2160,10 @@ static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw
     if constexpr (sizeof(T) == 2) {
         int pwl, tw, th, nt;
         if (!classes && c64_halo_gather(gp, N, ldw, ldc, ep, batch) && c64_halo_shape(gp.Hin, gp.Win, gp.M, &pwl, &tw, &th, &nt))
-            return launch_c64_halo(gp, (const bf16_t*)x, (const bf16_t*)w, N, ep, y, pwl, tw, th, nt, st);
+        {
+            HaloArgs ha{(int)(gp.M / ((int64_t)gp.Hin * gp.Win)), gp.Hin, gp.Win, pwl, tw, th, nt, N, N / 64, 1, 0, 0};
+            return launch_c64_halo<3, 3>(ha, (const bf16_t*)x, (const bf16_t*)w, ep, y, 2.0 * gp.M * N * 576, st);
+        }
     }
     if (classes) {                                        // class sets: stride-1 gathers without upsampling
         if (N <= 64) return launch_nt<T, 64, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
@@ -2260,7 +2271,19 @@ bool conv_fwd_up4_mfma_supported(const ConvGeom& g, int dtype) {
     return nt_shape_ok(g.Cin, g.Cout, (int64_t)g.B * g.H * g.W, dtype) && 4 * g.Cin >= (dtype == VAMD_BF16 ? 64 : 32);
 }
 
-int conv_fwd_up4_mfma_stats_parts(const ConvGeom& g) {
+// the four classes on the resident-filter kernel (64 stored channels, bf16): one class filter (32 KB) per workgroup
+static bool fwd_up4_halo(const ConvGeom& g, int dtype, int* pwl, int* tw, int* th, int* nt) {
+    static const int on = [] { const char* e = getenv("VAMD_UP4_HALO"); return e ? atoi(e) : 1; }();
+    if (!on || dtype != VAMD_BF16 || g.Cin != 64 || (g.Cout != 64 && g.Cout != 128)) return false;
+    if ((int64_t)g.M * g.Cout * 2 >= 0x7FFFFFF0ll) return false;
+    return c64_halo_shape(g.H, g.W, (int64_t)g.B * g.H * g.W, pwl, tw, th, nt);
+}
+
+int conv_fwd_up4_mfma_stats_parts(const ConvGeom& g, int dtype) {
+    {
+        int pwl, tw, th, nt;
+        if (fwd_up4_halo(g, dtype, &pwl, &tw, &th, &nt)) return c64_halo_blocks(nt, (g.Cout / 64) * 4) / (g.Cout / 64);
+    }
     ClassSet set;
     fwd_up4_classes(g, set);
     const int BN = g.Cout <= 64 ? 64 : 128;
@@ -2272,10 +2295,17 @@ int conv_fwd_up4_mfma_stats_parts(const ConvGeom& g) {
 
 int conv_fwd_up4_mfma(const ConvGeom& g, int dtype, const void* x, const void* w4, const float* bias,
                       const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st) {
+    Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats};
+    {
+        int pwl, tw, th, nt;
+        if (fwd_up4_halo(g, dtype, &pwl, &tw, &th, &nt)) {
+            HaloArgs ha{g.B, g.H, g.W, pwl, tw, th, nt, g.Cout, g.Cout / 64, 4, 2, (int64_t)g.Cout * 4 * g.Cin};
+            return launch_c64_halo<2, 2>(ha, (const bf16_t*)x, (const bf16_t*)w4, ep, y, 2.0 * g.M * g.Cout * 9.0 * g.Cin, st);
+        }
+    }
     ClassSet set;
     fwd_up4_classes(g, set);
     t_nominal_flops = 2.0 * g.M * g.Cout * 9.0 * g.Cin;
-    Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats};
     const int ldw = 4 * g.Cin;
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(set.g[0], x, w4, g.Cout, ldw, g.Cout, ep, y, 1, 0, 0, 0, st, &set);
     return run_nt<float>(set.g[0], x, w4, g.Cout, ldw, g.Cout, ep, y, 1, 0, 0, 0, st, &set);

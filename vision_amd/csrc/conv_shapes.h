@@ -59,7 +59,7 @@ int conv_fwd_short_mfma(const ConvGeom& g, int dtype, const void* x, const void*
                         const float* temb, const void* x2, const void* w2, int Cin2, const void* res2, void* y,
                         float* stats, hipStream_t st);
 bool conv_fwd_up4_mfma_supported(const ConvGeom& g, int dtype);
-int conv_fwd_up4_mfma_stats_parts(const ConvGeom& g);
+int conv_fwd_up4_mfma_stats_parts(const ConvGeom& g, int dtype);
 int conv_fwd_up4_mfma(const ConvGeom& g, int dtype, const void* x, const void* w4, const float* bias,
                       const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st);
 bool conv_dgrad_up4_mfma_supported(const ConvGeom& g, int dtype);
