@@ -256,3 +256,32 @@ def test_state_dict_roundtrip_and_checkpoint(golden, mode, tmp_path):
     m3 = vision_amd.DDPMModel.load_from_checkpoint(path, cfg)
     for k, v in load_file(path).items():
         assert torch.equal(m3.state_dict()[k], v), k
+
+
+def test_eval_batchnorm_coefficients_follow_state_changes(golden, mode):
+    """Eval-mode BatchNorm coefficients are cached between forwards (a sampler's steps): a new state, an
+    in-place edit of a running statistic and a training step must each show in the next eval forward."""
+    name, g, cfg, B = golden
+    if mode != "bf16-auto":
+        pytest.skip("host logic; one mode is enough")
+    x, t2 = g["x_t"].to(DEV), (g["sched_n"] ** 2).to(DEV)
+    m = make_model(cfg, sub(g, "state0"), mode).eval()
+    fresh3 = make_model(cfg, sub(g, "state3"), mode).eval()
+    with torch.no_grad():
+        y0 = m(x, t2)
+        assert torch.equal(m(x, t2), y0)                         # cached coefficients: same result
+        want3 = fresh3(x, t2)
+        m.load_state_dict(sub(g, "state3"))                      # other parameters AND running statistics
+        assert torch.equal(m(x, t2), want3)
+        key = next(k for k in m.state_dict() if k.endswith("running_var"))
+        m.state_dict()[key].mul_(4.0)                            # in-place edit of a buffer
+        y_edit = m(x, t2)
+        assert not torch.equal(y_edit, want3)
+        fresh3.state_dict()[key].mul_(4.0)
+        assert torch.equal(fresh3(x, t2), y_edit)
+    m.train()
+    loss = m.p_loss(g["x0"].to(DEV), g["eps"].to(DEV), g["t"].to(DEV))             # updates the running statistics
+    loss.backward()
+    m.eval()
+    with torch.no_grad():
+        assert not torch.equal(m(x, t2), y_edit)

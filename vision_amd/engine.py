@@ -216,6 +216,7 @@ class _Norm:
             self.rm, self.rv = eng.buffer(name + ".running_mean"), eng.buffer(name + ".running_var")
             self.nbt = eng.buffer(name + ".num_batches_tracked")
         self.slope = LEAKY_SLOPE if batchnorm else 1.0
+        self._eval_coef, self._eval_key = None, None
 
     def fwd(self, x, training, mask=None):
         B, H, W, Cc = x.shape
@@ -224,8 +225,16 @@ class _Norm:
         coef = torch.empty((4, G, Cc), dtype=torch.float32, device=dev)   # scale, shift, mean, rstd
         sc, sh, mu, rs = coef[0], coef[1], coef[2], coef[3]
         if self.bn and not training:
-            call("vamd_bn_finalize", None, 0, Cc, 0, _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm),
-                 _ptr(self.rv), None, BN_MOMENTUM, BN_EPS, 0, _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs), _stream())
+            # eval mode: the coefficients depend on parameters and running statistics only, so they are
+            # kept until either changes (a sampler calls this once per denoising step)
+            key = (e.coef_epoch, e.flat_b._version)
+            if self._eval_coef is not None and self._eval_key == key:
+                coef = self._eval_coef
+                sc, sh = coef[0], coef[1]
+            else:
+                call("vamd_bn_finalize", None, 0, Cc, 0, _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm),
+                     _ptr(self.rv), None, BN_MOMENTUM, BN_EPS, 0, _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs), _stream())
+                self._eval_coef, self._eval_key = coef, key
         else:
             fused = e.stats_for.pop(x.data_ptr(), None) if self.bn else None
             if fused is not None:                 # the producing convolution already summed y and y*y
@@ -527,6 +536,7 @@ class Engine:
         # (models/ddpm.py:126-134) on the host, once
         freqs = torch.exp(torch.linspace(math.log(1.0), math.log(1000.0), plan.ch // 2))
         self.angular = (2.0 * math.pi * freqs).to(self.device)
+        self.coef_epoch = 0
         self._lows = {spec.prefix: self._layer_low(spec.prefix) for spec in plan.layers}
         self._lows["End"] = self._layer_low("End")
         self.dirty = True
@@ -602,6 +612,7 @@ class Engine:
                     layer.refresh_bias()
             self._versions = vers
             self.dirty = False
+            self.coef_epoch += 1                              # parameters changed: cached eval-mode BatchNorm coefficients are stale
 
     def draw_dropout(self, shape, p):
         keep = torch.full(shape, 1.0 - p, dtype=torch.float32, device=self.device)
@@ -613,6 +624,8 @@ class Engine:
         Returns the NHWC prediction; if `tape` is a list it receives what backward needs."""
         self.refresh()
         self.stats_for.clear()
+        if training:
+            self.coef_epoch += 1                              # running statistics are about to change
         B = x.shape[0]
         drop_masks = drop_masks or {}
         emb = torch.empty((B, self.plan.ch), dtype=torch.float32, device=x.device)
