@@ -261,6 +261,18 @@ int vamd_timeembed(const float* t, const float* angular_speeds, float* emb, int 
  * The 1x1 convs on [B,C,1,1] maps at models/ddpm.py:156-157,215-217 and ResNetBlock.linear_temb (:47,77). */
 int vamd_linear_fwd(const float* x, const float* W, const float* bias, float* y, int B, int I,
                     int O, int act_in, float slope, void* stream);
+/* Several linear layers over the SAME input in one launch: every ResNetBlock's linear_temb
+ * (models/ddpm.py:47,77) projects the one time embedding of the step.  `items` is an array of n
+ * entries (n <= 64) in DEVICE memory; entry k writes y[b][o] for o < O, and `first` is the sum of
+ * the O of the entries before it (total_O = the sum over all entries). */
+typedef struct vamd_linear_item {
+    const float* W;        /* [O][I] */
+    const float* bias;     /* [O] or NULL */
+    float* y;              /* [B][O] */
+    int O, first;
+} vamd_linear_item;
+int vamd_linear_fwd_multi(const float* x, const vamd_linear_item* items, int n, int total_O, int B, int I,
+                          int act_in, float slope, void* stream);
 /* dx (may be NULL), dW, dbias of vamd_linear_fwd.  accumulate_dx: dx += instead of =. */
 int vamd_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW,
                     float* dbias, int B, int I, int O, int act_in, float slope,

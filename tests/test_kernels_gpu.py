@@ -614,3 +614,26 @@ def test_repack_weights_batched_matches_single(dts):
     for w, wf, wd, wf1, wd1 in keep:
         assert torch.equal(wf, wf1) and torch.equal(wd, wd1)
         assert torch.equal(wf.float(), w.permute(0, 2, 3, 1).to(tdt).float())
+
+
+def test_linear_fwd_multi_matches_single():
+    """Several linear layers over one input in one launch = the same layers one by one."""
+    from vision_amd._lib import LinearItem
+    gen = torch.Generator().manual_seed(5)
+    B, I, outs = 6, 96, [64, 40, 512, 8]
+    x = torch.randn((B, I), generator=gen).to(DEV)
+    Ws = [torch.randn((o, I), generator=gen).to(DEV) for o in outs]
+    bs = [torch.randn((o,), generator=gen).to(DEV) if k != 1 else None for k, o in enumerate(outs)]
+    ys = [torch.full((B, o), 7.0, device=DEV) for o in outs]
+    items, first = (LinearItem * len(outs))(), 0
+    for it, W, b, y, o in zip(items, Ws, bs, ys, outs):
+        it.W, it.bias, it.y, it.O, it.first = W.data_ptr(), (b.data_ptr() if b is not None else None), y.data_ptr(), o, first
+        first += o
+    table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(DEV)
+    call("vamd_linear_fwd_multi", P(x), P(table), len(outs), first, B, I, 1, 0.01, S())
+    for W, b, y, o in zip(Ws, bs, ys, outs):
+        one = torch.empty((B, o), device=DEV)
+        call("vamd_linear_fwd", P(x), P(W), P(b), P(one), B, I, o, 1, 0.01, S())
+        assert torch.equal(y, one)
+        ref = F.leaky_relu(x.double().cpu(), 0.01) @ W.double().cpu().T + (b.double().cpu() if b is not None else 0.0)
+        assert relerr(y, ref) < 1e-5

@@ -33,6 +33,10 @@ class RepackItem(C.Structure):
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("reserved", C.c_int32)]
 
 
+class LinearItem(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("O", C.c_int32), ("first", C.c_int32)]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build the HIP extension first (python vision_amd/build_ext.py). "
@@ -92,6 +96,7 @@ SIGNATURES = {
     "vamd_add": (_i, [_p, _p, _p, _l, _i, _p]),
     "vamd_timeembed": (_i, [_p, _p, _p, _i, _i, _p]),
     "vamd_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "vamd_linear_fwd_multi": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "vamd_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "vamd_qsample": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vamd_schedule": (_i, [_p, _p, _p, _p, _i, _p]),

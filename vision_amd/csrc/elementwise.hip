@@ -289,6 +289,30 @@ linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
     if (lane == 0) y[idx] = acc + (bias ? bias[o] : 0.f);
 }
 
+// wave per (b, output of some item): as linear_fwd_kernel, the item found by a scan of the (few) entries
+__global__ void __launch_bounds__(256)
+linear_fwd_multi_kernel(const float* __restrict__ x, const vamd_linear_item* __restrict__ items, int n,
+                        int total_O, int B, int I, int act_in, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= B * total_O) return;                           // wave-uniform
+    const int b = idx / total_O, og = idx - b * total_O;
+    int k = 0;
+    while (k + 1 < n && items[k + 1].first <= og) ++k;
+    const vamd_linear_item it = items[k];
+    const int o = og - it.first;
+    const float* xr = x + (int64_t)b * I;
+    const float* wr = it.W + (int64_t)o * I;
+    float acc = 0.f;
+    for (int i = lane; i < I; i += 64) {
+        float v = xr[i];
+        if (act_in) v = leaky(v, slope);
+        acc = fmaf(v, wr[i], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) it.y[(int64_t)b * it.O + o] = acc + (it.bias ? it.bias[o] : 0.f);
+}
+
 // block per (b, 16 inputs): 16 slices of the output features are reduced through LDS.
 // dx[b][i] = act'(x) * sum_o dy[b][o] W[o][i]
 __global__ void __launch_bounds__(256)
@@ -714,6 +738,17 @@ int vamd_linear_fwd(const float* x, const float* W, const float* bias, float* y,
     hipLaunchKernelGGL(linear_fwd_kernel, dim3((total + 3) / 4), dim3(256), 0, as_stream(stream),
                        x, W, bias, y, B, I, O, act_in, slope);
     VAMD_LAUNCH_OK("vamd_linear_fwd");
+    return 0;
+}
+
+int vamd_linear_fwd_multi(const float* x, const vamd_linear_item* items, int n, int total_O, int B, int I,
+                          int act_in, float slope, void* stream) {
+    VAMD_REQUIRE(x && items && n > 0 && n <= 64 && total_O > 0 && B > 0 && I > 0, "vamd_linear_fwd_multi: bad argument");
+    const int64_t total = (int64_t)B * total_O;
+    VAMD_REQUIRE(total < (1ll << 30), "vamd_linear_fwd_multi: too many outputs");
+    hipLaunchKernelGGL(linear_fwd_multi_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, as_stream(stream),
+                       x, items, n, total_O, B, I, act_in, slope);
+    VAMD_LAUNCH_OK("vamd_linear_fwd_multi");
     return 0;
 }
 

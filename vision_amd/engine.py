@@ -18,7 +18,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, RepackItem, call, lib
+from ._lib import ConvDesc, LinearItem, RepackItem, call, lib
 from .plan import LayerSpec, UNetPlan
 
 LEAKY_SLOPE = 0.01          # nn.LeakyReLU() default (reference models/ddpm.py:144)
@@ -317,7 +317,10 @@ class _ResBlock:
 
     def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
         a1, coef1 = self.bn1.fwd(x, training)
-        tproj = self.temb.fwd(temb)
+        # projected with the other blocks' in one launch, if this is the embedding that launch projected
+        tproj = self.eng.tproj_for.get(id(self)) if self.eng.tproj_src is temb else None
+        if tproj is None:
+            tproj = self.temb.fwd(temb)
         h1 = self.conv1.fwd(a1, temb=tproj, want_stats=training)
         mask = None
         if training and self.spec.dropout > 0.0:
@@ -537,6 +540,7 @@ class Engine:
         freqs = torch.exp(torch.linspace(math.log(1.0), math.log(1000.0), plan.ch // 2))
         self.angular = (2.0 * math.pi * freqs).to(self.device)
         self.coef_epoch = 0
+        self._tproj_cache, self.tproj_for, self.tproj_src = {}, {}, None
         self._lows = {spec.prefix: self._layer_low(spec.prefix) for spec in plan.layers}
         self._lows["End"] = self._layer_low("End")
         self.dirty = True
@@ -614,6 +618,33 @@ class Engine:
             self.dirty = False
             self.coef_epoch += 1                              # parameters changed: cached eval-mode BatchNorm coefficients are stale
 
+    def _project_temb(self, temb, B):
+        """Every ResNetBlock's projection of the step's time embedding (reference models/ddpm.py:77) in one
+        launch, into a buffer kept per batch size (the blocks read their slice as conv1's epilogue term;
+        nothing of it is needed by backward)."""
+        blocks = [l for l in self.layers if isinstance(l, _ResBlock)]
+        self.tproj_for, self.tproj_src = {}, None
+        if len(blocks) < 2 or len(blocks) > 64:
+            return
+        ent = self._tproj_cache.get(B)
+        if ent is None:
+            total = sum(l.spec.cout for l in blocks)
+            buf = torch.empty(B * total, dtype=torch.float32, device=self.device)
+            items = (LinearItem * len(blocks))()
+            views, first = [], 0
+            for it, l in zip(items, blocks):
+                v = buf[B * first:B * (first + l.spec.cout)].view(B, l.spec.cout)
+                it.W, it.bias, it.y, it.O, it.first = l.temb.w.data_ptr(), l.temb.b.data_ptr(), v.data_ptr(), l.spec.cout, first
+                views.append(v)
+                first += l.spec.cout
+            table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+            ent = (buf, table, views, total, blocks[0].temb.cin)
+            self._tproj_cache = {B: ent}                      # one batch size at a time is kept
+        buf, table, views, total, cin = ent
+        call("vamd_linear_fwd_multi", _ptr(temb), _ptr(table), len(blocks), total, B, cin, 1, LEAKY_SLOPE, _stream())
+        self.tproj_for = {id(l): v for l, v in zip(blocks, views)}
+        self.tproj_src = temb
+
     def draw_dropout(self, shape, p):
         keep = torch.full(shape, 1.0 - p, dtype=torch.float32, device=self.device)
         return (torch.bernoulli(keep, generator=self.drop_generator) / (1.0 - p)).to(self.dtype)
@@ -634,6 +665,7 @@ class Engine:
         temb = self.lin2.fwd(t1)
         if tape is not None:
             tape.append(("temb", (emb, t1, temb)))
+        self._project_temb(temb, B)
         skips: List[torch.Tensor] = []
         h = x
         nd, nm = self.n_down, self.n_mid
