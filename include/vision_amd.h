@@ -168,11 +168,13 @@ int vamd_stats_chunks(int64_t R, int G);
 int vamd_chan_stats(const void* x, float* partial, int G, int64_t R, int C, int dtype,
                     void* stream);
 /* As vamd_chan_stats, for the backward pass: sums of gz and gz*xhat where
- * z = x*scale+shift, gz = dy * mask * (z > 0 ? 1 : slope), xhat = (x - mean) * rstd.
- * scale/shift/mean/rstd are [G][C] fp32; mask may be NULL; slope = 1 disables the activation. */
+ * z = x*scale+shift, gz = dy * mask * mask_scale * (z > 0 ? 1 : slope), xhat = (x - mean) * rstd.
+ * scale/shift/mean/rstd are [G][C] fp32; mask may be NULL; slope = 1 disables the activation.
+ * mask_scale is the fp32 factor of nn.Dropout, 1/(1-p), so that the mask itself can hold exact
+ * 0/1 values in the compute dtype (1/0.9 is not a bf16 number). */
 int vamd_norm_bwd_stats(const void* dy, const void* x, const void* mask, const float* scale,
                         const float* shift, const float* mean, const float* rstd, float slope,
-                        float* partial, int G, int64_t R, int C, int dtype, void* stream);
+                        float mask_scale, float* partial, int G, int64_t R, int C, int dtype, void* stream);
 
 /* BatchNorm finalise (training = 1: batch statistics from `partial`, running statistics updated
  * with `momentum`, unbiased variance, num_batches_tracked += 1; training = 0: running statistics).
@@ -185,16 +187,17 @@ int vamd_bn_finalize(const float* partial, int nchunk, int C, int64_t count, con
 int vamd_gn_finalize(const float* partial, int nchunk, int B, int C, int groups, int64_t HW,
                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
                      float* mean, float* rstd, void* stream);
-/* y = leaky_relu(x*scale[g][c] + shift[g][c], slope) * mask.  slope = 1: no activation;
- * mask (pre-scaled dropout mask, same shape as x) may be NULL.
+/* y = leaky_relu(x*scale[g][c] + shift[g][c], slope) * mask * mask_scale.  slope = 1: no activation;
+ * mask (dropout keep mask, same shape as x) may be NULL.
  * Replaces BatchNorm2d/GroupNorm apply + nn.LeakyReLU (models/ddpm.py:51,57,144) + nn.Dropout (:58). */
 int vamd_scale_shift_act(const void* x, const float* scale, const float* shift, const void* mask,
-                         float slope, void* y, int G, int64_t R, int C, int dtype, void* stream);
+                         float slope, float mask_scale, void* y, int G, int64_t R, int C, int dtype, void* stream);
 /* Backward finalise for BatchNorm: dgamma, dbeta and the three per-channel coefficients of
- * dx = cA*gz + cB + cC*xhat. */
+ * dx = cA*gz + cB + cC*xhat.  fixed_stats = 1: the forward normalised with the running statistics
+ * (module in eval mode), mean and rstd are constants and cB = cC = 0. */
 int vamd_bn_bwd_finalize(const float* partial, int nchunk, int C, int64_t count,
                          const float* scale, float* dgamma, float* dbeta, float* cA, float* cB,
-                         float* cC, void* stream);
+                         float* cC, int fixed_stats, void* stream);
 /* BatchNorm backward statistics with the rows grouped per image, and a finalise that also returns
  * dsum[b][c] = sum over the pixels of image b of dx[b][.][c] (and dsum_total[c], may be NULL, its sum
  * over b) without reading dx: `partial` holds B * nchunk * C * 3 floats (sums of gz, gz*xhat and
@@ -203,10 +206,10 @@ int vamd_bn_bwd_finalize(const float* partial, int nchunk, int C, int64_t count,
  * to the tensor this BatchNorm normalises (models/ddpm.py:79-82), dsum_total that of conv1's bias. */
 int vamd_bn_bwd_stats_img(const void* dy, const void* x, const void* mask, const float* scale,
                           const float* shift, const float* mean, const float* rstd, float slope,
-                          float* partial, int B, int64_t HW, int C, int dtype, void* stream);
+                          float mask_scale, float* partial, int B, int64_t HW, int C, int dtype, void* stream);
 int vamd_bn_bwd_finalize_img(const float* partial, int nchunk, int B, int C, int64_t HW, const float* scale,
                              float* dgamma, float* dbeta, float* cA, float* cB, float* cC, float* dsum,
-                             float* dsum_total, void* stream);
+                             float* dsum_total, int fixed_stats, void* stream);
 /* Backward finalise for GroupNorm (coefficients are [B][C]). */
 int vamd_gn_bwd_finalize(const float* partial, int nchunk, int B, int C, int groups, int64_t HW,
                          const float* gamma, const float* rstd, float* dgamma, float* dbeta,
@@ -215,7 +218,7 @@ int vamd_gn_bwd_finalize(const float* partial, int nchunk, int B, int C, int gro
  * merge the other gradient streams reaching x (residual shortcut, UNet skip). */
 int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const float* scale,
                         const float* shift, const float* mean, const float* rstd, float slope,
-                        const float* cA, const float* cB, const float* cC, const void* add,
+                        float mask_scale, const float* cA, const float* cB, const float* cC, const void* add,
                         const void* add2, void* dx, int G, int64_t R, int C, int dtype,
                         void* stream);
 /* Sums partial [G][nchunk][C][2] to per_g[G][C] (component 0) and total[C] = sum over g.

@@ -8,6 +8,7 @@ last.safetensors) -> checkpoint callback -> fit -> rank-0 test.
 `--synthetic` replaces the ImageFolder on disk by ImageFolder-shaped random batches.
 """
 import argparse
+import datetime
 import os
 import shutil
 
@@ -31,8 +32,10 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
+        # a collective some rank never joins ends the job with an error after this long instead of hanging
+        dist.init_process_group(os.environ.get("VAMD_DIST_BACKEND", "nccl"),
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("VAMD_DIST_TIMEOUT_S", "600"))))
     rank = dist.get_rank() if dist.is_initialized() else 0
 
     data_cls = SyntheticImageFolder if args.synthetic else ImageFolderDataModule
@@ -65,7 +68,9 @@ def main():
     trainer.fit(model, datamodule=data_module)
 
     if rank == 0:
-        Trainer(devices=1, num_nodes=1, logger=logger, precision=config["trainer_config"].get("precision", "16-mixed")) \
+        # rank 0 alone, like the reference (run.py:93-96): a trainer that takes no part in the process group
+        Trainer(devices=1, num_nodes=1, logger=logger, distributed=False,
+                precision=config["trainer_config"].get("precision", "16-mixed")) \
             .test(model, data_module.test_dataloader(), verbose=True)
         if os.path.exists("lightning_logs"):
             shutil.rmtree("lightning_logs")

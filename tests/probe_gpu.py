@@ -1,5 +1,6 @@
 """Diagnostics (not a pytest file): dumps what ds_read_b64_tr_b16 and the 16x16x32 bf16 MFMA
-deliver per lane, to confirm the layouts the kernels assume.  python tests/probe_gpu.py"""
+deliver per lane, to confirm the layouts the kernels assume.  The probes live in a library of their
+own, not in the product's:  python vision_amd/build_ext.py --probe && python tests/probe_gpu.py"""
 import ctypes as C
 import os
 import sys
@@ -7,7 +8,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vision_amd._lib import lib  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = C.CDLL(os.path.join(ROOT, "vision_amd", "lib", "libvamd_probe.so"))
 
 dev = torch.device("cuda:0")
 out = torch.zeros(256, dtype=torch.int16, device=dev)

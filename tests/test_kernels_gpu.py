@@ -363,7 +363,8 @@ def test_batchnorm_act_fwd_bwd(shape, dts):
     mask, mask64 = rnd((B, Cc, H, W), tdt, gen)
     g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
     rm64, rv64 = rm.double().clone(), rv.double().clone()
-    y64 = F.leaky_relu(F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5), 0.01) * mask64
+    MS = 1.25                                    # fp32 factor applied on top of the mask (dropout's 1/(1-p))
+    y64 = F.leaky_relu(F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5), 0.01) * mask64 * MS
 
     R = B * H * W
     nchunk = lib.vamd_stats_chunks(R, 1)
@@ -376,7 +377,7 @@ def test_batchnorm_act_fwd_bwd(shape, dts):
          P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), S())
     y = torch.empty_like(x)
     maskn = nhwc(mask)
-    call("vamd_scale_shift_act", P(x), P(coef[0]), P(coef[1]), P(maskn), 0.01, P(y), 1, R, Cc, dt, S())
+    call("vamd_scale_shift_act", P(x), P(coef[0]), P(coef[1]), P(maskn), 0.01, MS, P(y), 1, R, Cc, dt, S())
     assert relerr(y.permute(0, 3, 1, 2), y64.detach()) < TOL_OUT[dts]
     assert relerr(rmd, rm64) < 1e-5 and relerr(rvd, rv64) < 1e-5 and int(nbt) == 1
 
@@ -384,12 +385,12 @@ def test_batchnorm_act_fwd_bwd(shape, dts):
     gx, gg, gb = torch.autograd.grad(y64, [x64, g64, b64], dy64)
     add, add64 = rnd((B, Cc, H, W), tdt, gen)
     dyn = nhwc(dy)
-    call("vamd_norm_bwd_stats", P(dyn), P(x), P(maskn), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01,
+    call("vamd_norm_bwd_stats", P(dyn), P(x), P(maskn), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01, MS,
          P(part), 1, R, Cc, dt, S())
     out = torch.empty((5, Cc), dtype=torch.float32, device=DEV)
-    call("vamd_bn_bwd_finalize", P(part), nchunk, Cc, R, P(coef[0]), P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(out[4]), S())
+    call("vamd_bn_bwd_finalize", P(part), nchunk, Cc, R, P(coef[0]), P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(out[4]), 0, S())
     dx = torch.empty_like(x)
-    call("vamd_norm_bwd_apply", P(dyn), P(x), P(maskn), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01,
+    call("vamd_norm_bwd_apply", P(dyn), P(x), P(maskn), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01, MS,
          P(out[2]), P(out[3]), P(out[4]), P(nhwc(add)), None, P(dx), 1, R, Cc, dt, S())
     assert relerr(out[0], gg) < 2e-4 and relerr(out[1], gb) < 2e-4
     assert relerr(dx.permute(0, 3, 1, 2), gx + add64) < TOL_OUT[dts]
@@ -398,13 +399,13 @@ def test_batchnorm_act_fwd_bwd(shape, dts):
     # channel sums of dx (exact ones, of the fp64 gradient) without a pass over dx
     nck = lib.vamd_stats_chunks(H * W, B)
     part3 = torch.empty((B, nck, Cc, 3), dtype=torch.float32, device=DEV)
-    call("vamd_bn_bwd_stats_img", P(dyn), P(x), P(maskn), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01,
+    call("vamd_bn_bwd_stats_img", P(dyn), P(x), P(maskn), P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01, MS,
          P(part3), B, H * W, Cc, dt, S())
     out2 = torch.empty((5, Cc), dtype=torch.float32, device=DEV)
     dsum = torch.empty((B, Cc), dtype=torch.float32, device=DEV)
     dtot = torch.empty((Cc,), dtype=torch.float32, device=DEV)
     call("vamd_bn_bwd_finalize_img", P(part3), nck, B, Cc, H * W, P(coef[0]), P(out2[0]), P(out2[1]), P(out2[2]),
-         P(out2[3]), P(out2[4]), P(dsum), P(dtot), S())
+         P(out2[3]), P(out2[4]), P(dsum), P(dtot), 0, S())
     assert relerr(out2, out) < 1e-5
     ref_sum = gx.sum(dim=(2, 3))
     scale_ref = float(gx.abs().sum(dim=(2, 3)).max())      # the sums cancel: measure against the summed magnitudes
@@ -414,10 +415,29 @@ def test_batchnorm_act_fwd_bwd(shape, dts):
     # eval mode: running statistics
     call("vamd_bn_finalize", None, 0, Cc, 0, P(gm), P(bt), P(rmd), P(rvd), None, 0.1, 1e-5, 0,
          P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), S())
-    call("vamd_scale_shift_act", P(x), P(coef[0]), P(coef[1]), None, 0.01, P(y), 1, R, Cc, dt, S())
-    ye = F.leaky_relu(F.batch_norm(x64.detach(), rmd.double().cpu(), rvd.double().cpu(), gamma.double(), beta.double(),
-                                   False, 0.1, 1e-5), 0.01)
-    assert relerr(y.permute(0, 3, 1, 2), ye) < TOL_OUT[dts]
+    call("vamd_scale_shift_act", P(x), P(coef[0]), P(coef[1]), None, 0.01, 1.0, P(y), 1, R, Cc, dt, S())
+    xe = x64.detach().clone().requires_grad_(True)
+    ge, be = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ye = F.leaky_relu(F.batch_norm(xe, rmd.double().cpu(), rvd.double().cpu(), ge, be, False, 0.1, 1e-5), 0.01)
+    assert relerr(y.permute(0, 3, 1, 2), ye.detach()) < TOL_OUT[dts]
+    # eval-mode backward: the running statistics are constants, dx = scale * gz (fixed_stats = 1), in both
+    # forms of the statistics pass; dsum is then the per-image channel sum of that dx
+    gxe, gge, gbe = torch.autograd.grad(ye, [xe, ge, be], dy64)
+    call("vamd_norm_bwd_stats", P(dyn), P(x), None, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01, 1.0,
+         P(part), 1, R, Cc, dt, S())
+    call("vamd_bn_bwd_finalize", P(part), nchunk, Cc, R, P(coef[0]), P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(out[4]), 1, S())
+    call("vamd_norm_bwd_apply", P(dyn), P(x), None, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01, 1.0,
+         P(out[2]), P(out[3]), P(out[4]), None, None, P(dx), 1, R, Cc, dt, S())
+    assert relerr(out[0], gge) < 2e-4 and relerr(out[1], gbe) < 2e-4
+    assert relerr(dx.permute(0, 3, 1, 2), gxe) < TOL_OUT[dts]
+    call("vamd_bn_bwd_stats_img", P(dyn), P(x), None, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 0.01, 1.0,
+         P(part3), B, H * W, Cc, dt, S())
+    call("vamd_bn_bwd_finalize_img", P(part3), nck, B, Cc, H * W, P(coef[0]), P(out2[0]), P(out2[1]), P(out2[2]),
+         P(out2[3]), P(out2[4]), P(dsum), P(dtot), 1, S())
+    assert relerr(out2, out) < 1e-5
+    ref_sum = gxe.sum(dim=(2, 3))
+    scale_ref = float(gxe.abs().sum(dim=(2, 3)).max())
+    assert float((dsum.double().cpu() - ref_sum).abs().max()) < (2e-5 if dts == "f32" else 2e-2) * scale_ref
 
 
 @pytest.mark.parametrize("dts", ["f32", "bf16"])
@@ -440,17 +460,17 @@ def test_groupnorm_fwd_bwd(shape, dts):
     gm, bt = gamma.to(DEV), beta.to(DEV)
     call("vamd_gn_finalize", P(part), nchunk, B, Cc, 32, R, P(gm), P(bt), 1e-6, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), S())
     y = torch.empty_like(x)
-    call("vamd_scale_shift_act", P(x), P(coef[0]), P(coef[1]), None, 1.0, P(y), B, R, Cc, dt, S())
+    call("vamd_scale_shift_act", P(x), P(coef[0]), P(coef[1]), None, 1.0, 1.0, P(y), B, R, Cc, dt, S())
     assert relerr(y.permute(0, 3, 1, 2), y64.detach()) < TOL_OUT[dts]
     dy, dy64 = rnd((B, Cc, H, W), tdt, gen)
     gx, gg, gb = torch.autograd.grad(y64, [x64, g64, b64], dy64)
     dyn = nhwc(dy)
-    call("vamd_norm_bwd_stats", P(dyn), P(x), None, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 1.0, P(part), B, R, Cc, dt, S())
+    call("vamd_norm_bwd_stats", P(dyn), P(x), None, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 1.0, 1.0, P(part), B, R, Cc, dt, S())
     dgb = torch.empty((2, Cc), dtype=torch.float32, device=DEV)
     abc = torch.empty((3, B, Cc), dtype=torch.float32, device=DEV)
     call("vamd_gn_bwd_finalize", P(part), nchunk, B, Cc, 32, R, P(gm), P(coef[3]), P(dgb[0]), P(dgb[1]), P(abc[0]), P(abc[1]), P(abc[2]), S())
     dx = torch.empty_like(x)
-    call("vamd_norm_bwd_apply", P(dyn), P(x), None, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 1.0,
+    call("vamd_norm_bwd_apply", P(dyn), P(x), None, P(coef[0]), P(coef[1]), P(coef[2]), P(coef[3]), 1.0, 1.0,
          P(abc[0]), P(abc[1]), P(abc[2]), None, None, P(dx), B, R, Cc, dt, S())
     assert relerr(dgb[0], gg) < 2e-4 and relerr(dgb[1], gb) < 2e-4
     assert relerr(dx.permute(0, 3, 1, 2), gx) < TOL_OUT[dts]

@@ -77,15 +77,15 @@ SIGNATURES = {
     "vamd_unpack_wgrad": (_i, [_p, _p, _i, _i, _i, _p]),
     "vamd_stats_chunks": (_i, [_l, _i]),
     "vamd_chan_stats": (_i, [_p, _p, _i, _l, _i, _i, _p]),
-    "vamd_norm_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _i, _p]),
+    "vamd_norm_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _l, _i, _i, _p]),
     "vamd_bn_finalize": (_i, [_p, _i, _i, _l, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
     "vamd_gn_finalize": (_i, [_p, _i, _i, _i, _i, _l, _p, _p, _f, _p, _p, _p, _p, _p]),
-    "vamd_scale_shift_act": (_i, [_p, _p, _p, _p, _f, _p, _i, _l, _i, _i, _p]),
-    "vamd_bn_bwd_finalize": (_i, [_p, _i, _i, _l, _p, _p, _p, _p, _p, _p, _p]),
-    "vamd_bn_bwd_stats_img": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _i, _p]),
-    "vamd_bn_bwd_finalize_img": (_i, [_p, _i, _i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "vamd_scale_shift_act": (_i, [_p, _p, _p, _p, _f, _f, _p, _i, _l, _i, _i, _p]),
+    "vamd_bn_bwd_finalize": (_i, [_p, _i, _i, _l, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "vamd_bn_bwd_stats_img": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _l, _i, _i, _p]),
+    "vamd_bn_bwd_finalize_img": (_i, [_p, _i, _i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "vamd_gn_bwd_finalize": (_i, [_p, _i, _i, _i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "vamd_norm_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p]),
+    "vamd_norm_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p]),
     "vamd_sum_finalize": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "vamd_bmm_nt": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
     "vamd_bmm_tn": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),

@@ -21,6 +21,9 @@
 #ifndef VAMD_ABLATE
 #define VAMD_ABLATE 0        // 1..4, 10, 11 / 5..7 / 8: timing-only experiments on the wide / the 128-row / the weight-gradient kernel (results are wrong)
 #endif
+#if VAMD_ABLATE != 0 && !defined(VAMD_TIMING_ONLY_BUILD)
+#error "VAMD_ABLATE variants compute wrong results: build them with `build_ext.py --variant NAME -DVAMD_ABLATE=n` (a separately named library), never into libvision_amd.so"
+#endif
 
 namespace vamd {
 

@@ -47,6 +47,7 @@ struct NormBwdArgs {
     const float* mean;
     const float* rstd;
     float slope;
+    float mask_scale;     // dropout: mask holds 0/1 (or any weights), multiplied by this fp32 factor (1/(1-p))
 };
 
 // MODE 0: accumulates (x, x*x).  MODE 1: accumulates (gz, gz*xhat) for the backward pass.
@@ -113,7 +114,7 @@ chan_stats_kernel(const T* __restrict__ x, NormBwdArgs a, float* __restrict__ pa
                 } else {
                     const float z = fmaf(xf, sc[j], sh[j]);
                     float gz = to_f(dv[j]);
-                    if (mk) gz *= to_f(mv[j]);
+                    if (mk) gz *= to_f(mv[j]) * a.mask_scale;
                     if (!(z > 0.f)) gz *= a.slope;
                     const float xh = (xf - mu[j]) * rs[j];
                     s1[j] += gz;
@@ -227,7 +228,7 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunk, int C,
                                        double count, const float* __restrict__ scale,
                                        float* dgamma, float* dbeta, float* cA, float* cB,
-                                       float* cC) {
+                                       float* cC, int fixed_stats) {
     const int c = blockIdx.x;                      // one wave per channel
     double s1, s2;
     reduce_parts(partial, nchunk, C, c, s1, s2);
@@ -236,8 +237,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nc
     dgamma[c] = (float)s2;
     const double sc = (double)scale[c];
     cA[c] = (float)sc;
-    cB[c] = (float)(-sc * s1 / count);
-    cC[c] = (float)(-sc * s2 / count);
+    // fixed_stats: mean and rstd are constants (eval-mode running statistics), so dx = scale * gz only
+    cB[c] = fixed_stats ? 0.f : (float)(-sc * s1 / count);
+    cC[c] = fixed_stats ? 0.f : (float)(-sc * s2 / count);
 }
 
 // BatchNorm backward from per-image partial sums [B][nchunk][C][3] = (gz, gz*xhat, xhat): the usual
@@ -248,7 +250,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nc
 __global__ void bn_bwd_finalize_img_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
                                            double hw, const float* __restrict__ scale, float* dgamma,
                                            float* dbeta, float* cA, float* cB, float* cC,
-                                           float* __restrict__ dsum, float* __restrict__ dsum_total) {
+                                           float* __restrict__ dsum, float* __restrict__ dsum_total,
+                                           int fixed_stats) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double t1 = 0.0, t2 = 0.0;
     for (int b = lane; b < B; b += 64) {
@@ -261,7 +264,7 @@ __global__ void bn_bwd_finalize_img_kernel(const float* __restrict__ partial, in
     const double s1 = wave_sum_d(t1), s2 = wave_sum_d(t2);
     const double count = hw * B;
     const double sc = (double)scale[c];
-    const double a = sc, bq = -sc * s1 / count, cq = -sc * s2 / count;
+    const double a = sc, bq = fixed_stats ? 0.0 : -sc * s1 / count, cq = fixed_stats ? 0.0 : -sc * s2 / count;
     double tot = 0.0;
     for (int b = lane; b < B; b += 64) {
         double g1 = 0.0, g3 = 0.0;
@@ -358,7 +361,7 @@ fold_partials_kernel(const float* __restrict__ in, int nparts, int width, int no
 template <typename T, int VEC, bool HOIST>
 __global__ void scale_shift_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                        const float* __restrict__ shift, const T* __restrict__ mask,
-                                       float slope, T* __restrict__ y, int64_t RC, int C,
+                                       float slope, float mask_scale, T* __restrict__ y, int64_t RC, int C,
                                        int64_t nvec) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -385,7 +388,7 @@ __global__ void scale_shift_act_kernel(const T* __restrict__ x, const float* __r
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float z = leaky(fmaf(to_f(xv[j]), sc[j], sh[j]), slope);
-            if (mask) z *= to_f(mv[j]);
+            if (mask) z *= to_f(mv[j]) * mask_scale;
             yv[j] = from_f<T>(z);
         }
         if (VEC > 1) *reinterpret_cast<Vec16<T>*>(y + e) = *reinterpret_cast<Vec16<T>*>(yv);
@@ -399,6 +402,7 @@ struct NormApplyArgs {
     const float* cA; const float* cB; const float* cC;
     const void* add; const void* add2;
     float slope;
+    float mask_scale;
 };
 
 // HOIST: one group (BatchNorm) and a grid stride that is a multiple of C, so a lane keeps its VEC
@@ -445,7 +449,7 @@ __global__ void norm_bwd_apply_kernel(NormApplyArgs a, T* __restrict__ dx, int64
             const float xf = to_f(xv[j]);
             const float z = fmaf(xf, sc[j], sh[j]);
             float gz = to_f(dv[j]);
-            if (mask) gz *= to_f(mv[j]);
+            if (mask) gz *= to_f(mv[j]) * a.mask_scale;
             if (!(z > 0.f)) gz *= a.slope;
             const float xh = (xf - mu[j]) * rs[j];
             float r = fmaf(cA[j], gz, fmaf(cC[j], xh, cB[j]));
@@ -502,12 +506,12 @@ int vamd_chan_stats(const void* x, float* partial, int G, int64_t R, int C, int 
 
 int vamd_norm_bwd_stats(const void* dy, const void* x, const void* mask, const float* scale,
                         const float* shift, const float* mean, const float* rstd, float slope,
-                        float* partial, int G, int64_t R, int C, int dtype, void* stream) {
+                        float mask_scale, float* partial, int G, int64_t R, int C, int dtype, void* stream) {
     VAMD_REQUIRE(dy && x && scale && shift && mean && rstd && partial, "vamd_norm_bwd_stats: null pointer");
     VAMD_REQUIRE(G > 0 && G <= 65535 && R > 0 && C > 0, "vamd_norm_bwd_stats: bad shape");
     VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)mask % 16 == 0,
                  "vamd_norm_bwd_stats: tensors must be 16-byte aligned");
-    NormBwdArgs a{dy, mask, scale, shift, mean, rstd, slope};
+    NormBwdArgs a{dy, mask, scale, shift, mean, rstd, slope, mask_scale};
     VAMD_DISPATCH(dtype, "vamd_norm_bwd_stats", {
         int rc = launch_stats<T, 1>("vamd_norm_bwd_stats", (const T*)x, a, partial, G, R, C, as_stream(stream));
         if (rc) return rc;
@@ -518,12 +522,12 @@ int vamd_norm_bwd_stats(const void* dy, const void* x, const void* mask, const f
 
 int vamd_bn_bwd_stats_img(const void* dy, const void* x, const void* mask, const float* scale,
                           const float* shift, const float* mean, const float* rstd, float slope,
-                          float* partial, int B, int64_t HW, int C, int dtype, void* stream) {
+                          float mask_scale, float* partial, int B, int64_t HW, int C, int dtype, void* stream) {
     VAMD_REQUIRE(dy && x && scale && shift && mean && rstd && partial, "vamd_bn_bwd_stats_img: null pointer");
     VAMD_REQUIRE(B > 0 && B <= 65535 && HW > 0 && C > 0, "vamd_bn_bwd_stats_img: bad shape");
     VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)mask % 16 == 0,
                  "vamd_bn_bwd_stats_img: tensors must be 16-byte aligned");
-    NormBwdArgs a{dy, mask, scale, shift, mean, rstd, slope};
+    NormBwdArgs a{dy, mask, scale, shift, mean, rstd, slope, mask_scale};
     VAMD_DISPATCH(dtype, "vamd_bn_bwd_stats_img", {
         int rc = launch_stats<T, 2>("vamd_bn_bwd_stats_img", (const T*)x, a, partial, B, HW, C, as_stream(stream));
         if (rc) return rc;
@@ -534,11 +538,11 @@ int vamd_bn_bwd_stats_img(const void* dy, const void* x, const void* mask, const
 
 int vamd_bn_bwd_finalize_img(const float* partial, int nchunk, int B, int C, int64_t HW, const float* scale,
                              float* dgamma, float* dbeta, float* cA, float* cB, float* cC, float* dsum,
-                             float* dsum_total, void* stream) {
+                             float* dsum_total, int fixed_stats, void* stream) {
     VAMD_REQUIRE(partial && scale && dgamma && dbeta && cA && cB && cC && dsum && nchunk > 0 && B > 0 && C > 0 && HW > 0,
                  "vamd_bn_bwd_finalize_img: bad argument");
     hipLaunchKernelGGL(bn_bwd_finalize_img_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, nchunk, B, C,
-                       (double)HW, scale, dgamma, dbeta, cA, cB, cC, dsum, dsum_total);
+                       (double)HW, scale, dgamma, dbeta, cA, cB, cC, dsum, dsum_total, fixed_stats);
     VAMD_LAUNCH_OK("vamd_bn_bwd_finalize_img");
     return 0;
 }
@@ -572,7 +576,7 @@ int vamd_gn_finalize(const float* partial, int nchunk, int B, int C, int groups,
 }
 
 int vamd_scale_shift_act(const void* x, const float* scale, const float* shift, const void* mask,
-                         float slope, void* y, int G, int64_t R, int C, int dtype, void* stream) {
+                         float slope, float mask_scale, void* y, int G, int64_t R, int C, int dtype, void* stream) {
     VAMD_REQUIRE(x && scale && shift && y && G > 0 && R > 0 && C > 0, "vamd_scale_shift_act: bad argument");
     VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)mask % 16 == 0,
                  "vamd_scale_shift_act: tensors must be 16-byte aligned");
@@ -582,15 +586,15 @@ int vamd_scale_shift_act(const void* x, const float* scale, const float* shift, 
         if (C % VEC == 0) {
             if (G == 1 && (256 * VEC) % C == 0)
                 hipLaunchKernelGGL((scale_shift_act_kernel<T, VEC, true>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
-                                   as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope,
+                                   as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope, mask_scale,
                                    (T*)y, R * C, C, n / VEC);
             else
                 hipLaunchKernelGGL((scale_shift_act_kernel<T, VEC, false>), dim3(grid_for(n / VEC, 256)), dim3(256), 0,
-                                   as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope,
+                                   as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope, mask_scale,
                                    (T*)y, R * C, C, n / VEC);
         } else {
             hipLaunchKernelGGL((scale_shift_act_kernel<T, 1, false>), dim3(grid_for(n, 256)), dim3(256), 0,
-                               as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope,
+                               as_stream(stream), (const T*)x, scale, shift, (const T*)mask, slope, mask_scale,
                                (T*)y, R * C, C, n);
         }
     });
@@ -599,11 +603,12 @@ int vamd_scale_shift_act(const void* x, const float* scale, const float* shift, 
 }
 
 int vamd_bn_bwd_finalize(const float* partial, int nchunk, int C, int64_t count, const float* scale,
-                         float* dgamma, float* dbeta, float* cA, float* cB, float* cC, void* stream) {
+                         float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int fixed_stats,
+                         void* stream) {
     VAMD_REQUIRE(partial && scale && dgamma && dbeta && cA && cB && cC && nchunk > 0 && C > 0 && count > 0,
                  "vamd_bn_bwd_finalize: bad argument");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, as_stream(stream),
-                       partial, nchunk, C, (double)count, scale, dgamma, dbeta, cA, cB, cC);
+                       partial, nchunk, C, (double)count, scale, dgamma, dbeta, cA, cB, cC, fixed_stats);
     VAMD_LAUNCH_OK("vamd_bn_bwd_finalize");
     return 0;
 }
@@ -625,7 +630,7 @@ int vamd_gn_bwd_finalize(const float* partial, int nchunk, int B, int C, int gro
 
 int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const float* scale,
                         const float* shift, const float* mean, const float* rstd, float slope,
-                        const float* cA, const float* cB, const float* cC, const void* add,
+                        float mask_scale, const float* cA, const float* cB, const float* cC, const void* add,
                         const void* add2, void* dx, int G, int64_t R, int C, int dtype,
                         void* stream) {
     VAMD_REQUIRE(dy && x && scale && shift && mean && rstd && cA && cB && cC && dx,
@@ -634,7 +639,7 @@ int vamd_norm_bwd_apply(const void* dy, const void* x, const void* mask, const f
     VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 &&
                      (uintptr_t)mask % 16 == 0 && (uintptr_t)add % 16 == 0 && (uintptr_t)add2 % 16 == 0,
                  "vamd_norm_bwd_apply: tensors must be 16-byte aligned");
-    NormApplyArgs a{dy, x, mask, scale, shift, mean, rstd, cA, cB, cC, add, add2, slope};
+    NormApplyArgs a{dy, x, mask, scale, shift, mean, rstd, cA, cB, cC, add, add2, slope, mask_scale};
     const int64_t n = (int64_t)G * R * C;
     VAMD_DISPATCH(dtype, "vamd_norm_bwd_apply", {
         constexpr int VEC = Vec16<T>::N;

@@ -74,6 +74,9 @@ class _UNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, t, anchor):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise RuntimeError("vision_amd computes parameter gradients only: the network input x and the time t "
+                               "must not require grad")
         eng = model._ensure_engine()
         B, Cc, H, W = x.shape
         xn = torch.empty((B, H, W, Cc), dtype=eng.dtype, device=x.device)
@@ -101,6 +104,9 @@ class _PLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, images, noises, times, anchor):
+        if any(ctx.needs_input_grad[1:4]):
+            raise RuntimeError("vision_amd computes parameter gradients only: images, noises and diffusion times "
+                               "must not require grad")
         eng = model._ensure_engine()
         B, Cc, H, W = images.shape
         dev = images.device
@@ -190,9 +196,10 @@ class DDPMModel(LightningModule):
         return eng
 
     def set_dropout_masks(self, masks):
-        """Testing hook: {'Middle.0': mask, 'Middle.2': mask} (NHWC, pre-scaled by 1/(1-p)) used by
-        the next training forward instead of fresh Bernoulli draws."""
-        self._drop_masks = masks
+        """Testing hook: {'Middle.0': mask, 'Middle.2': mask} (NHWC; non-zero = keep, so both 0/1 masks
+        and nn.Dropout's outputs pre-scaled by 1/(1-p) are accepted) used by the next training forward
+        instead of fresh Bernoulli draws."""
+        self._drop_masks = None if masks is None else {k: (v != 0).to(v.dtype) for k, v in masks.items()}
 
     def _pop_drop_masks(self):
         m, self._drop_masks = self._drop_masks, None

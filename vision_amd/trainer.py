@@ -91,6 +91,7 @@ class ImageFolderDataModule:
                  test_split=0.1, use_manual_split=False, device="cpu", **_):
         self.data_dir, self.patch_size, self.batch_size = data_dir, patch_size, batch_size
         self.val_split, self.test_split, self.use_manual_split, self.device = val_split, test_split, use_manual_split, device
+        self._epoch_seed = 0
 
     def _scan(self, root):
         classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
@@ -120,10 +121,30 @@ class ImageFolderDataModule:
         img = Image.open(path).convert("RGB").resize((self.patch_size, self.patch_size), Image.BILINEAR)
         return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
 
+    @staticmethod
+    def shard(order, rank, world):
+        """Rank `rank`'s share of `order`, the same length on every rank: the list is padded with its own
+        head up to a multiple of `world` and dealt round-robin (what torch's DistributedSampler does with
+        drop_last=False, which Lightning injects for the reference under DDP).  Ranks that ran a different
+        number of batches would leave the gradient all-reduce of the longest one without partners."""
+        if world <= 1 or not order:
+            return list(order)
+        total = -(-len(order) // world) * world
+        padded = list(order)
+        while len(padded) < total:
+            padded += order[:total - len(padded)]
+        return padded[rank:total:world]
+
     def _loader(self, split, shuffle, rank=0, world=1):
         items = self.splits[split]
-        order = torch.randperm(len(items)).tolist() if shuffle else list(range(len(items)))
-        order = order[rank::world] if world > 1 else order
+        if shuffle:
+            # every rank must deal from the same permutation: draw it from a generator seeded alike
+            g = torch.Generator().manual_seed(self._epoch_seed)
+            self._epoch_seed += 1
+            order = torch.randperm(len(items), generator=g).tolist()
+        else:
+            order = list(range(len(items)))
+        order = self.shard(order, rank, world)
         for i in range(0, len(order), self.batch_size):
             chunk = [items[j] for j in order[i:i + self.batch_size]]
             x = torch.stack([self._load(p) for p, _ in chunk])
@@ -146,13 +167,17 @@ class Trainer:
 
     def __init__(self, logger: Optional[DirLogger] = None, callbacks=(), max_epochs=1, precision="16-mixed",
                  accelerator="gpu", devices=1, max_steps=-1, limit_val_batches=None, log_every_n_steps=1,
-                 enable_checkpointing=False, enable_progress_bar=False, num_nodes=1, **_):
+                 enable_checkpointing=False, enable_progress_bar=False, num_nodes=1, distributed=True, **_):
+        """distributed=False: a single-process trainer even when a process group is up (no broadcasts, no
+        scalar all-reduce) - what the reference's rank-0 `Trainer(devices=1).test(...)` after fit is
+        (run.py:93-96); with the group's collectives it would wait for ranks that never call them."""
         self.logger, self.callbacks = logger, list(callbacks)
         self.max_epochs, self.max_steps, self.limit_val_batches = max_epochs, max_steps, limit_val_batches
         self.precision = _PRECISIONS.get(precision, "bf16")
         self.current_epoch, self.global_step = 0, 0
         self.callback_metrics = {}
-        self.global_rank, self.world_size = world_info()
+        self.distributed = bool(distributed)
+        self.global_rank, self.world_size = world_info() if self.distributed else (0, 1)
         self.lightning_module = None
         self._epoch_sums = {}
         self.dp: Optional[DataParallel] = None
@@ -177,7 +202,9 @@ class Trainer:
         return out
 
     def _attach(self, model):
-        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))) if torch.cuda.is_available() else None
+        # ranks beyond the device count wrap around (several gloo ranks rehearsing on one GPU)
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count()) \
+            if torch.cuda.is_available() else None
         if device is None:
             raise RuntimeError("vision_amd needs an MI355X (HIP device); no CPU path exists")
         torch.cuda.set_device(device)
@@ -185,7 +212,13 @@ class Trainer:
         model.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[self.precision]
         model.trainer, model.logger = self, self.logger
         self.lightning_module = model
-        self.dp = DataParallel(model)
+        if self.distributed:
+            self.dp = DataParallel(model)
+        else:
+            # no exchange of any kind: detach a reducer an earlier distributed trainer may have left
+            self.dp = None
+            model.grad_reducer = None
+            model._ensure_engine().reducer = None
         return device
 
     def fit(self, model, datamodule):
@@ -193,6 +226,11 @@ class Trainer:
         datamodule.device = device
         datamodule.setup()
         cfg = model.configure_optimizers()
+        if cfg is None:
+            # the reference returns None when scheduler_gamma is present but null (models/ddpm.py:347-352),
+            # which Lightning reads as "no optimizer"; training cannot proceed, so say why
+            raise ValueError("configure_optimizers() returned None (scheduler_gamma is null in model_config): "
+                             "set a number, or remove the key to train with the bare optimizer")
         if isinstance(cfg, tuple):
             (opt,), scheds = cfg
         else:
@@ -205,7 +243,8 @@ class Trainer:
             self.current_epoch = epoch
             model.train()
             for i, batch in enumerate(datamodule.train_dataloader(self.global_rank, self.world_size)):
-                self.dp.broadcast_buffers()
+                if self.dp is not None:
+                    self.dp.broadcast_buffers()
                 loss = model.training_step(batch, i)
                 loss.backward()
                 opt.step()
