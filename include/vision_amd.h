@@ -39,9 +39,11 @@ int vamd_version(void);
  * launch) and forgets earlier records; vamd_launch_timing(0) stops recording.
  * vamd_launch_timing_read waits for the recorded launches of `kind` (0: forward / input-gradient
  * kernel, 1: weight-gradient kernel) to finish - the one call of this library that blocks - and
- * returns their number, summed duration in ms and summed algorithmic FLOPs (2*M*N*K each). */
+ * returns their number, summed duration in ms, summed algorithmic FLOPs (2*M*N*K of the operator each)
+ * and, in executed_flops (may be NULL), what the launches really multiplied: less than the operator's
+ * count for the combined-filter forms of the upsampling convolution. */
 int vamd_launch_timing(int enable);
-long vamd_launch_timing_read(int kind, double* total_ms, double* total_flops);
+long vamd_launch_timing_read(int kind, double* total_ms, double* total_flops, double* executed_flops);
 
 /* ------------------------------------------------------------------ convolution
  * One descriptor for nn.Conv2d 3x3 pad 1 stride 1|2, 1x1 pad 0, and "nearest 2x upsample then
@@ -187,6 +189,18 @@ int vamd_bn_finalize(const float* partial, int nchunk, int C, int64_t count, con
 int vamd_gn_finalize(const float* partial, int nchunk, int B, int C, int groups, int64_t HW,
                      const float* gamma, const float* beta, float eps, float* scale, float* shift,
                      float* mean, float* rstd, void* stream);
+/* Allocation-free GroupNorm coefficients: vamd_chan_stats + vamd_gn_finalize in one call, with the partial
+ * sums kept in a buffer built into the library instead of a workspace the caller allocates.  It has no
+ * counterpart in the reference; it is for callers that cannot allocate device memory: code under HIP
+ * graph capture, tight sampling loops, harnesses that forbid hipMalloc.  x is [B][HW][C] in `dtype`;
+ * outputs are [B][C] fp32, bit-identical to the two-call form.  The built-in buffer holds
+ * VAMD_GN_NOALLOC_SCRATCH_BYTES per GPU (kept until the process ends); a shape whose partial sums
+ * (B * vamd_stats_chunks(HW, B) * C * 2 floats) do not fit is rejected with VAMD_EINVAL.  Calls on one GPU
+ * share that GPU's buffer: calls that overlap in time on one GPU (different streams, threads) race. */
+#define VAMD_GN_NOALLOC_SCRATCH_BYTES (8u << 20)
+int vamd_gn_coef_noalloc(const void* x, int B, int C, int groups, int64_t HW, const float* gamma,
+                         const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
+                         int dtype, void* stream);
 /* y = leaky_relu(x*scale[g][c] + shift[g][c], slope) * mask * mask_scale.  slope = 1: no activation;
  * mask (dropout keep mask, same shape as x) may be NULL.
  * Replaces BatchNorm2d/GroupNorm apply + nn.LeakyReLU (models/ddpm.py:51,57,144) + nn.Dropout (:58). */

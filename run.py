@@ -2,10 +2,11 @@
 data module -> versioned logger -> seed -> model (optionally resumed from the previous version's
 last.safetensors) -> checkpoint callback -> fit -> rank-0 test.
 
-    python run.py --config configs/butterfly_ddpm.yaml [--synthetic] [--max-steps N]
+    python run.py --config configs/butterfly_ddpm.yaml [--synthetic] [--max-steps N] [--save-dir DIR]
     python -m torch.distributed.run --nproc-per-node 8 run.py --config ...   (data parallel)
 
-`--synthetic` replaces the ImageFolder on disk by ImageFolder-shaped random batches.
+`--synthetic` replaces the ImageFolder on disk by ImageFolder-shaped random batches; `--save-dir`
+overrides `log_config.save_dir`.
 """
 import argparse
 import datetime
@@ -21,14 +22,17 @@ from vision_amd.trainer import DirLogger, ImageFolderDataModule, SyntheticImageF
 from vision_amd.utils import SafetensorsCheckpoint
 
 
-def main():
+def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("--config", dest="filename", default="configs/flowers_ddpm.yaml")
     parser.add_argument("--synthetic", action="store_true")
     parser.add_argument("--max-steps", type=int, default=-1)
-    args = parser.parse_args()
+    parser.add_argument("--save-dir", default=None)
+    args = parser.parse_args(argv)
     with open(args.filename, "r") as f:
         config = yaml.safe_load(f)
+    if args.save_dir is not None:
+        config["log_config"]["save_dir"] = args.save_dir
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
@@ -76,7 +80,9 @@ def main():
             shutil.rmtree("lightning_logs")
     if dist.is_initialized():
         dist.barrier()
-        dist.destroy_process_group()
+        if world > 1:
+            dist.destroy_process_group()
+    return model, logger
 
 
 if __name__ == "__main__":

@@ -185,3 +185,41 @@ def test_flops_model_counts_every_conv():
     b = train_flops_per_image(get_preset("butterfly")["model_config"])
     h = train_flops_per_image(get_preset("ffhq")["model_config"])
     assert 1e11 < f < 2e11 and b == f and h > 5 * f
+
+
+@pytest.mark.parametrize("n,world", [(10, 4), (7, 2), (3, 4), (8, 2), (0, 2), (5, 1)])
+def test_imagefolder_shards_have_equal_length_on_every_rank(n, world):
+    """Per-rank index lists like DistributedSampler(drop_last=False): padded with the head of the list to a
+    multiple of the world size, so every rank runs the same number of batches (and collectives)."""
+    from vision_amd.trainer import ImageFolderDataModule
+    order = list(range(100, 100 + n))
+    parts = [ImageFolderDataModule.shard(order, r, world) for r in range(world)]
+    assert len({len(p) for p in parts}) == 1
+    assert len(parts[0]) == (-(-n // world) if world > 1 else n)
+    flat = [i for p in parts for i in p]
+    assert set(flat) == set(order)                          # nothing dropped
+    if n:
+        assert max(flat.count(i) for i in order) - min(flat.count(i) for i in order) <= (1 if n >= world else world)
+
+
+def test_imagefolder_datamodule_on_disk(tmp_path):
+    """Class sub-directories of PNGs -> Resize + ToTensor batches in [0, 1], 80/10/10 split, and the same
+    shuffled order on every rank of an epoch (the permutation is drawn from a per-epoch seed)."""
+    from PIL import Image
+    import numpy as np
+    from vision_amd.trainer import ImageFolderDataModule
+    rng = np.random.default_rng(0)
+    for c in ("a", "b"):
+        os.makedirs(tmp_path / c)
+        for i in range(10):
+            Image.fromarray(rng.integers(0, 256, (12, 9, 3), dtype=np.uint8)).save(tmp_path / c / f"{i}.png")
+    dm = ImageFolderDataModule(str(tmp_path), patch_size=8, batch_size=3, use_manual_split=True)
+    dm.setup()
+    assert dm.num_classes == 2 and {k: len(v) for k, v in dm.splits.items()} == {"train": 16, "valid": 2, "test": 2}
+    r0 = list(dm.train_dataloader(0, 2))
+    dm._epoch_seed = 0
+    r1 = list(dm.train_dataloader(1, 2))
+    assert len(r0) == len(r1) == 3 and [b[0].shape[0] for b in r0] == [3, 3, 2]
+    x, y = r0[0]
+    assert x.shape == (3, 3, 8, 8) and x.dtype == torch.float32 and 0.0 <= float(x.min()) and float(x.max()) <= 1.0
+    assert y.dtype == torch.int64

@@ -144,3 +144,35 @@ def test_rccl_path_with_one_rank_group():
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0
     assert 0.0 < res["final_loss"] < 10.0
+
+
+def test_run_py_with_two_ranks_fits_and_tests_on_rank0(tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 run.py`: both ranks fit (sharded synthetic batches, gradient
+    all-reduce, scalar all-reduce of the logged losses), then rank 0 ALONE runs the test pass with a trainer
+    that takes no part in the process group while rank 1 waits in the final barrier (reference run.py:93-103).
+    Two gloo ranks share this GPU; a rank-0-only collective would leave the job hanging until the timeout."""
+    import json
+    import subprocess
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _, cfg, _ = load_golden("t1")
+    config = {
+        "model_config": cfg,
+        "data_config": {"patch_size": cfg["patch_size"], "data_dir": "unused", "batch_size": 4, "length": 100},
+        "trainer_config": {"accelerator": "gpu", "devices": 2, "max_epochs": 1, "precision": "32"},
+        "log_config": {"name": "dp2", "save_dir": str(tmp_path / "logs"), "checkpoint": True, "model_summary": False},
+    }
+    path = tmp_path / "dp2.yaml"
+    path.write_text(yaml.safe_dump(config, sort_keys=False))
+    env = dict(os.environ, VAMD_DIST_BACKEND="gloo", VAMD_DIST_TIMEOUT_S="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "run.py"),
+           "--config", str(path), "--synthetic"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "TeL" in out.stdout
+    v0 = tmp_path / "logs" / "dp2" / "version_0"
+    rows = [json.loads(l) for l in open(v0 / "metrics.jsonl")]
+    assert len(rows) == 1 and rows[0]["step"] == 10         # 80 training images / 2 ranks / batch 4
+    assert (v0 / "checkpoints" / "last.safetensors").exists()

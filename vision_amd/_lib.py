@@ -52,7 +52,7 @@ SIGNATURES = {
     "vamd_last_error": (C.c_char_p, []),
     "vamd_version": (_i, []),
     "vamd_launch_timing": (_i, [_i]),
-    "vamd_launch_timing_read": (C.c_long, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vamd_launch_timing_read": (C.c_long, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vamd_conv2d_fwd": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vamd_conv2d_fwd_stats": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vamd_conv2d_stats_parts": (_i, [_d]),
@@ -80,6 +80,7 @@ SIGNATURES = {
     "vamd_norm_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _l, _i, _i, _p]),
     "vamd_bn_finalize": (_i, [_p, _i, _i, _l, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),
     "vamd_gn_finalize": (_i, [_p, _i, _i, _i, _i, _l, _p, _p, _f, _p, _p, _p, _p, _p]),
+    "vamd_gn_coef_noalloc": (_i, [_p, _i, _i, _i, _l, _p, _p, _f, _p, _p, _p, _p, _i, _p]),
     "vamd_scale_shift_act": (_i, [_p, _p, _p, _p, _f, _f, _p, _i, _l, _i, _i, _p]),
     "vamd_bn_bwd_finalize": (_i, [_p, _i, _i, _l, _p, _p, _p, _p, _p, _p, _i, _p]),
     "vamd_bn_bwd_stats_img": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _l, _i, _i, _p]),
@@ -113,6 +114,18 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+def source_hash():
+    """sha256 over the kernel sources and the header: profile summaries are stamped with it, so a reader can
+    tell whether a committed counter pass still describes the kernels in the tree."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join(_HERE, "..", "include", "vision_amd.h")]:
+        with open(f if os.path.isabs(f) or f.startswith(_HERE) else os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc, what=""):

@@ -41,12 +41,15 @@ int fail(int code, const char* fmt, ...);
 
 // Launch timing (vamd_launch_timing): while switched on, a TimedLaunch on the stack of a launcher
 // records one HIP event right before and one right after the kernel launch it brackets.
-int timed_launch_begin(int kind, double flops, hipStream_t st);     // slot index or -1 when off
+int timed_launch_begin(int kind, double flops, double executed, hipStream_t st);     // slot index or -1 when off
 void timed_launch_end(int slot, hipStream_t st);
 struct TimedLaunch {
     int slot;
     hipStream_t st;
-    TimedLaunch(int kind, double flops, hipStream_t s) : slot(timed_launch_begin(kind, flops, s)), st(s) {}
+    // flops: the operator's algorithmic count; executed: what the launch really multiplies (they differ for
+    // the combined-filter forms of the upsampling convolution)
+    TimedLaunch(int kind, double flops, double executed, hipStream_t s)
+        : slot(timed_launch_begin(kind, flops, executed, s)), st(s) {}
     ~TimedLaunch() { if (slot >= 0) timed_launch_end(slot, st); }
 };
 enum { TIMED_NT = 0, TIMED_TN = 1 };

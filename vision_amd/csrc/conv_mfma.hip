@@ -2033,7 +2033,7 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
                 blocks = plan_classes(256, 256 / n_tiles > 0 ? 256 / n_tiles : 1, &flops);
                 for (int c = 0; c < cs.ncls; ++c) cs.stats_off[c] = (int64_t)(cs.first_block[c] / n_tiles) * N * 2;
             }
-            TimedLaunch timed(TIMED_NT, take_flops(flops), st);
+            TimedLaunch timed(TIMED_NT, take_flops(flops), flops, st);
             if (ep.stats)
                 hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, true>), dim3(blocks), dim3(512), LDS_W, st, gp,
                                    x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
@@ -2059,7 +2059,7 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
         blocks = plan_classes(kBM, per_column > 0 ? per_column : 1, &flops);
         for (int c = 0; c < cs.ncls; ++c) cs.stats_off[c] = (int64_t)(cs.first_block[c] / n_tiles) * N * 2;
     }
-    TimedLaunch timed(TIMED_NT, take_flops(flops), st);
+    TimedLaunch timed(TIMED_NT, take_flops(flops), flops, st);
     if (ep.stats)
         hipLaunchKernelGGL((conv_ntp_mfma_kernel<T, BN, UP, true>), dim3(blocks), dim3(256), LDS_PIPE, st, gp, x,
                            w, N, ldw, ldc, ep, y, m_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
@@ -2096,7 +2096,7 @@ static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ld
     const int n_tiles = N / 256, mw_tiles = (gp.M + 255) / 256;
     const int row_tiles = mw_tiles * batch;
     const int groups = ntp_row_groups(row_tiles, n_tiles, 1);
-    TimedLaunch timed(TIMED_NT, take_flops(2.0 * gp.M * N * gp.Ktot * batch), st);
+    TimedLaunch timed(TIMED_NT, take_flops(2.0 * gp.M * N * gp.Ktot * batch), 2.0 * gp.M * N * gp.Ktot * batch, st);
     ClassSet cs;
     cs.ncls = 0;
     if (ep.stats)
@@ -2149,7 +2149,7 @@ static int launch_c64_halo(const HaloArgs& ha, const bf16_t* x, const bf16_t* w,
         configured = true;
     }
     const int blocks = c64_halo_blocks(ha.ntiles, ha.n_tiles * ha.ncls);
-    TimedLaunch timed(TIMED_NT, take_flops(flops), st);
+    TimedLaunch timed(TIMED_NT, take_flops(flops), flops, st);
     if (ep.stats) hipLaunchKernelGGL((conv_c64_halo_kernel<true, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
     else hipLaunchKernelGGL((conv_c64_halo_kernel<false, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
     VAMD_LAUNCH_OK("conv_c64_halo");
@@ -2582,7 +2582,7 @@ static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int
     int slices = 1, steps_per = total_steps;
     if (out_mode == 0) tn_split(n_tiles * f_tiles, total_steps, &slices, &steps_per);
     dim3 grid(n_tiles * f_tiles * slices, 1, batch);
-    TimedLaunch timed(TIMED_TN, take_flops(2.0 * gp.M * N * gp.Ktot * batch), st);
+    TimedLaunch timed(TIMED_TN, take_flops(2.0 * gp.M * N * gp.Ktot * batch), 2.0 * gp.M * N * gp.Ktot * batch, st);
     hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
                        f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode);
     VAMD_LAUNCH_OK("conv_tn_mfma");

@@ -10,13 +10,13 @@ namespace vamd {
 static thread_local char g_err[512] = "";
 
 // ---- launch timing ----------------------------------------------------------------------------
-struct TimedSlot { hipEvent_t e0, e1; int kind; double flops; };
+struct TimedSlot { hipEvent_t e0, e1; int kind; double flops, executed; };
 static std::mutex g_timed_mu;
 static std::vector<TimedSlot> g_timed;       // events are created once and reused
 static size_t g_timed_used = 0;
 static bool g_timed_on = false;
 
-int timed_launch_begin(int kind, double flops, hipStream_t st) {
+int timed_launch_begin(int kind, double flops, double executed, hipStream_t st) {
     if (!g_timed_on) return -1;
     std::lock_guard<std::mutex> lk(g_timed_mu);
     if (g_timed_used == g_timed.size()) {
@@ -27,6 +27,7 @@ int timed_launch_begin(int kind, double flops, hipStream_t st) {
     TimedSlot& s = g_timed[g_timed_used];
     s.kind = kind;
     s.flops = flops;
+    s.executed = executed;
     if (hipEventRecord(s.e0, st) != hipSuccess) return -1;
     return (int)g_timed_used++;
 }
@@ -564,9 +565,9 @@ int vamd_launch_timing(int enable) {
     return 0;
 }
 
-long vamd_launch_timing_read(int kind, double* total_ms, double* total_flops) {
+long vamd_launch_timing_read(int kind, double* total_ms, double* total_flops, double* executed_flops) {
     std::lock_guard<std::mutex> lk(g_timed_mu);
-    double ms = 0.0, fl = 0.0;
+    double ms = 0.0, fl = 0.0, ex = 0.0;
     long n = 0;
     for (size_t i = 0; i < g_timed_used; ++i) {
         const TimedSlot& s = g_timed[i];
@@ -577,10 +578,12 @@ long vamd_launch_timing_read(int kind, double* total_ms, double* total_flops) {
         if (e != hipSuccess) return -(long)fail((int)e, "vamd_launch_timing_read: %s", hipGetErrorString(e));
         ms += t;
         fl += s.flops;
+        ex += s.executed;
         ++n;
     }
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
+    if (executed_flops) *executed_flops = ex;
     return n;
 }
 

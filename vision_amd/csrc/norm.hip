@@ -4,6 +4,8 @@
 // inputs once with 16-byte accesses and reduces in registers -> LDS -> one partial row per block.
 #include "common.h"
 
+#include <mutex>
+
 namespace vamd {
 
 constexpr int kStatsBlock = 256;
@@ -484,6 +486,36 @@ static int launch_stats(const char* name, const T* x, NormBwdArgs a, float* part
     return 0;
 }
 
+// ---- allocation-free GroupNorm statistics ------------------------------------------------------
+// Partial sums of vamd_gn_coef_noalloc live in this array instead of a caller-supplied workspace.
+// Every GPU the library runs on holds its own copy at its own address until the process ends.
+constexpr size_t kGnScratchFloats = VAMD_GN_NOALLOC_SCRATCH_BYTES / sizeof(float);
+static __device__ __align__(256) float g_gn_scratch[kGnScratchFloats];
+
+constexpr int kMaxDevices = 64;
+static float* g_gn_scratch_ptr[kMaxDevices];          // device address of g_gn_scratch, per device ordinal
+static std::mutex g_gn_scratch_mu;
+
+// The array's name is only a host-side handle: the device address comes from hipGetSymbolAddress, once
+// per device, with that device current.
+static int gn_scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail((int)e, "vamd_gn_coef_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return fail(VAMD_EUNSUPPORTED, "vamd_gn_coef_noalloc: device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_gn_scratch_mu);
+    if (!g_gn_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_gn_scratch));
+        if (e != hipSuccess || !p)
+            return fail(e != hipSuccess ? (int)e : VAMD_EUNSUPPORTED, "vamd_gn_coef_noalloc: hipGetSymbolAddress: %s",
+                        hipGetErrorString(e));
+        g_gn_scratch_ptr[dev] = reinterpret_cast<float*>(p);
+    }
+    *out = g_gn_scratch_ptr[dev];
+    return 0;
+}
+
 }  // namespace vamd
 
 using namespace vamd;
@@ -572,6 +604,37 @@ int vamd_gn_finalize(const float* partial, int nchunk, int B, int C, int groups,
                        partial, nchunk, B, C, groups, (double)HW * (C / groups), gamma, beta, eps,
                        scale, shift, mean, rstd);
     VAMD_LAUNCH_OK("vamd_gn_finalize");
+    return 0;
+}
+
+int vamd_gn_coef_noalloc(const void* x, int B, int C, int groups, int64_t HW, const float* gamma,
+                         const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,
+                         int dtype, void* stream) {
+    VAMD_REQUIRE(x && gamma && beta && scale && shift && mean && rstd, "vamd_gn_coef_noalloc: null pointer");
+    VAMD_REQUIRE(B > 0 && B <= 65535 && C > 0 && groups > 0 && C % groups == 0 && HW > 0,
+                 "vamd_gn_coef_noalloc: bad shape (B=%d C=%d groups=%d)", B, C, groups);
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0, "vamd_gn_coef_noalloc: x must be 16-byte aligned");
+    const int nchunk = stats_chunks(HW, B);
+    const size_t need = (size_t)B * nchunk * C * 2;
+    if (need > kGnScratchFloats)
+        return fail(VAMD_EINVAL, "vamd_gn_coef_noalloc: B=%d HW=%lld C=%d needs %zu bytes of partial sums, the built-in "
+                    "buffer holds %zu (VAMD_GN_NOALLOC_SCRATCH_BYTES); use vamd_chan_stats + vamd_gn_finalize with a "
+                    "workspace of your own", B, (long long)HW, C, need * sizeof(float), (size_t)VAMD_GN_NOALLOC_SCRATCH_BYTES);
+    float* partial = nullptr;
+    int rc = gn_scratch_for_current_device(&partial);
+    if (rc) return rc;
+    // every partial row that the finalise kernel reads is written by the statistics kernel of the same call,
+    // so nothing has to be cleared between calls
+    NormBwdArgs a{};
+    VAMD_DISPATCH(dtype, "vamd_gn_coef_noalloc", {
+        rc = launch_stats<T, 0>("vamd_gn_coef_noalloc", (const T*)x, a, partial, B, HW, C, as_stream(stream));
+        if (rc) return rc;
+    });
+    const int total = B * groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 63) / 64), dim3(64), 0, as_stream(stream),
+                       partial, nchunk, B, C, groups, (double)HW * (C / groups), gamma, beta, eps,
+                       scale, shift, mean, rstd);
+    VAMD_LAUNCH_OK("vamd_gn_coef_noalloc");
     return 0;
 }
 
