@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
-    ap.add_argument("--sample-steps", type=int, default=10)
+    ap.add_argument("--sample-steps", type=int, default=None,
+                    help="denoising steps of the timed sampling run (default 10; 1000 for --preset ffhq, as BASELINE names it)")
     return ap.parse_args()
 
 
@@ -115,6 +116,8 @@ def trace(msg):
 
 def main():
     args = parse()
+    if args.sample_steps is None:
+        args.sample_steps = 1000 if args.preset == "ffhq" else 10
     if os.environ.get("VAMD_BENCH_TRACE"):
         import faulthandler
         faulthandler.dump_traceback_later(45, exit=False)
