@@ -56,7 +56,15 @@ typedef struct vamd_conv_desc {
     int32_t upsample;  /* 1: input is read through a nearest-neighbour 2x upsample */
     int32_t dtype;     /* VAMD_F32 | VAMD_BF16 (activations and packed weights) */
     int32_t algo;      /* 0 auto (thin -> MFMA -> direct), 1 direct, 2 MFMA, 3 thin-channel kernels */
+    /* Optional, may be NULL / 0: device memory of the caller's that forward / input-gradient kernels may use
+     * to even out their work over the compute units (partial sums of tiles whose reduction is split between
+     * workgroups).  VAMD_CONV_SCRATCH_BYTES is enough for every shape.  The caller zero-fills it ONCE after
+     * allocating it and does not touch it afterwards; launches that share one scratch buffer must be ordered
+     * (one stream).  Results with and without it differ in the summation order of the split tiles only. */
+    void* scratch;
+    uint64_t scratch_bytes;
 } vamd_conv_desc;
+#define VAMD_CONV_SCRATCH_BYTES (4096u + 256u * 256u * 256u * 4u)
 
 /* y = conv(x, w) + bias[c] + temb[b][c] + residual + residual2; each addend may be NULL.
  * residual2 carries the UNet skip tensor that the reference adds in place to the input of the

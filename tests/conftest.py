@@ -45,3 +45,18 @@ def noise_keys(tensors):
 @pytest.fixture(scope="session", params=["t0", "t1", "t0_drop"])
 def golden(request):
     return (request.param,) + load_golden(request.param)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _conv_scratch_for_every_descriptor():
+    """VAMD_TEST_SCRATCH=1: every ConvDesc the tests build carries a scratch buffer, so that the kernels that can
+    split tiles between workgroups do so in all kernel tests (otherwise only the tests that ask for it)."""
+    if os.environ.get("VAMD_TEST_SCRATCH") != "1":
+        yield
+        return
+    import torch
+    from vision_amd import _lib
+    buf = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device="cuda:0")
+    _lib.set_default_scratch(buf)
+    yield
+    _lib.set_default_scratch(None)

@@ -36,6 +36,8 @@ def timeit(fn, iters=10):
 
 
 def main():
+    if os.environ.get("PERF_SCRATCH", "1") != "0":        # let the wide kernels split tiles, as the engine does
+        _lib.set_default_scratch(torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=DEV))
     cases = sys.argv[1:] or DEFAULT
     st = torch.cuda.current_stream().cuda_stream
     for cs in cases:

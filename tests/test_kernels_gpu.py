@@ -111,6 +111,91 @@ CONV_CASES = [
 ]
 
 
+# Shapes the ping-pong kernel takes at its default thresholds with a scratch buffer: the row tiles' reduction is
+# then split between workgroups (every CU an equal share of K-tiles; tiles that straddle shares are summed from
+# partial results).  B, H, W, Cin, Cout, k, stride, up
+SPLIT_CASES = [
+    (4, 56, 56, 256, 256, 3, 1, 0),       # 49 tiles of 256 x 256 on 256 workgroups: every tile split 5 ways
+    (2, 112, 112, 128, 128, 3, 1, 0),     # 49 tiles of 512 x 128
+    (8, 28, 28, 256, 512, 3, 1, 0),       # two column tiles: 25 row tiles each on 128 workgroups
+    (32, 14, 14, 512, 512, 3, 1, 1),      # upsampling conv: its input gradient is a 4 x 4 stride-2 conv (K = 16 * 512)
+    (7, 223, 111, 128, 128, 3, 2, 0),     # stride 2, ragged last tile
+]
+
+# Shapes with enough tiles (>= 200) for the ping-pong kernel to take them as whole tiles without any scratch buffer.
+WIDE_CASES = [
+    (8, 128, 128, 64, 128, 3, 1, 0),      # 256 tiles of 512 x 128
+    (4, 128, 128, 128, 256, 3, 1, 0),     # 256 tiles of 256 x 256 (reduction of 1152: the longest this tile serves)
+    (17, 223, 111, 128, 128, 3, 2, 0),    # stride 2, 209 tiles, ragged last tile
+    (8, 128, 128, 128, 128, 1, 1, 0),     # 1 x 1: four K-tiles per tile, as many as the load ring has stages
+    (8, 128, 128, 64, 128, 1, 1, 0),      # two K-tiles per tile
+    (8, 128, 128, 32, 256, 1, 1, 0),      # one K-tile per tile
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES + WIDE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_wide_tiles(case):
+    """Forward (with bias, time embedding, residual, skip and fused BatchNorm statistics) and input gradient with the
+    descriptor's optional scratch buffer against fp64, and against the same calls without it (whole tiles): the
+    two differ in fp32 summation order only.  Run twice: the flags of the first launch must not satisfy the second."""
+    split = os.environ.get("VAMD_NT8_STREAMK") == "1"      # split shares are opt-in: at these sizes they cost what they save
+    if not split and case in SPLIT_CASES:
+        pytest.skip("too few tiles for the whole-tile form of the kernel; the split form needs VAMD_NT8_STREAMK=1")
+    B, H, W, Cin, Cout, k, stride, up = case
+    tdt, dt = DT["bf16"]
+    gen = torch.Generator().manual_seed(sum(case))
+    pad = 1 if k == 3 else 0
+    x, x64 = rnd((B, Cin, H, W), tdt, gen)
+    _, w64 = rnd((Cout, Cin, k, k), tdt, gen, 1.0 / math.sqrt(Cin * k * k))
+    wf, wd = pack_weights(w64, tdt, dt)
+    bias, temb = torch.randn(Cout, generator=gen), torch.randn(B, Cout, generator=gen)
+    x64 = x64.requires_grad_(True)
+    y64 = conv_ref(x64, w64, stride, up, k)
+    res, res64 = rnd(tuple(y64.shape), tdt, gen)
+    res2, res264 = rnd(tuple(y64.shape), tdt, gen)
+    dy, dy64 = rnd(tuple(y64.shape), tdt, gen)
+    add, add64 = rnd((B, Cin, H, W), tdt, gen)
+    want = y64.detach() + bias.double()[None, :, None, None] + temb.double()[:, :, None, None] + res64 + res264
+    (gx,) = torch.autograd.grad(y64, [x64], dy64)
+    xn, dyn, resn, res2n, addn = nhwc(x), nhwc(dy), nhwc(res), nhwc(res2), nhwc(add)
+    Ho, Wo = y64.shape[2], y64.shape[3]
+    scratch = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=DEV)
+    outs = {}
+    for name, sc in (("plain", None), ("split", scratch), ("split again", scratch))[:3 if split else 1]:
+        d = ConvDesc(B, H, W, Cin, Cout, k, stride, pad, up, dt, _lib.ALGO_MFMA)
+        if sc is not None:
+            d.scratch, d.scratch_bytes = sc.data_ptr(), sc.numel()
+        nparts = lib.vamd_conv2d_stats_parts(C.byref(d))
+        y = torch.full((B, Ho, Wo, Cout), 7.0, dtype=tdt, device=DEV)
+        if up:                                   # the upsampling forward runs as four classes on other kernels
+            call("vamd_conv2d_fwd", C.byref(d), P(xn), P(wf), P(bias.to(DEV)), P(temb.to(DEV)), P(resn), P(res2n), P(y), S())
+        else:
+            assert nparts > 0
+            part = torch.full((nparts, Cout, 2), 7.0, dtype=torch.float32, device=DEV)
+            call("vamd_conv2d_fwd_stats", C.byref(d), P(xn), P(wf), P(bias.to(DEV)), P(temb.to(DEV)), P(resn), P(res2n), P(y),
+                 P(part), S())
+            yd = y.double().cpu().reshape(-1, Cout)
+            assert relerr(part.sum(0), torch.stack([yd.sum(0), (yd * yd).sum(0)], 1)) < 1e-5, name
+        assert relerr(y.permute(0, 3, 1, 2), want) < TOL_OUT["bf16"], name
+        dx = torch.full((B, H, W, Cin), 7.0, dtype=tdt, device=DEV)
+        if up and lib.vamd_conv2d_dgrad_up4_supported(C.byref(d)):
+            wd4 = torch.empty((Cin, 4, 4, Cout), dtype=tdt, device=DEV)
+            call("vamd_repack_weight_up4", P(w64.float().to(DEV).contiguous()), P(wd4), Cout, Cin, dt, S())
+            call("vamd_conv2d_dgrad_up4", C.byref(d), P(dyn), P(wd4), P(addn), P(dx), S())
+        else:
+            nb = lib.vamd_conv2d_dgrad_workspace(C.byref(d))
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+            call("vamd_conv2d_dgrad", C.byref(d), P(dyn), P(wd), P(addn), P(dx), P(ws), nb, S())
+        assert relerr(dx.permute(0, 3, 1, 2), gx + add64) < TOL_OUT["bf16"], name
+        outs[name] = (y, dx)
+    if not split:
+        return
+    # same inputs, same split: bit-reproducible; against whole tiles: rounding of a different summation order
+    assert torch.equal(outs["split"][0], outs["split again"][0]) and torch.equal(outs["split"][1], outs["split again"][1])
+    assert relerr(outs["split"][0], outs["plain"][0].double()) < 2e-3
+    assert relerr(outs["split"][1], outs["plain"][1].double()) < 2e-3
+
+
 def conv_ref(x64, w64, stride, up, k):
     if up:
         x64 = F.interpolate(x64, scale_factor=2, mode="nearest")
@@ -259,6 +344,8 @@ def test_conv_fwd_with_shortcut_source(case, dts):
     if dts == "bf16" and (Cin, Cout, k) == (64, 64, 3) and os.environ.get("VAMD_C64_HALO_MIN") == "1":
         assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2) == 0
         pytest.skip("the resident-filter kernel is forced for this shape; it has no second source")
+    if os.environ.get("VAMD_NT8_MIN") == "1" and lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2) == 0:
+        pytest.skip("the ping-pong kernel is forced for this shape; it has no second source")
     assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2) == 1
     assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2 + 8) == 0
     x, x64 = rnd((B, Cin, H, W), tdt, gen)

@@ -23,9 +23,28 @@ class VamdError(RuntimeError):
     pass
 
 
+_DEFAULT_SCRATCH = None      # (tensor, nbytes) attached to every new ConvDesc (set_default_scratch)
+
+
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("B", "H", "W", "Cin", "Cout", "ksize", "stride", "pad", "upsample", "dtype", "algo")]
+                ("B", "H", "W", "Cin", "Cout", "ksize", "stride", "pad", "upsample", "dtype", "algo")] + \
+               [("scratch", C.c_void_p), ("scratch_bytes", C.c_uint64)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if _DEFAULT_SCRATCH is not None and not self.scratch:
+            self.scratch, self.scratch_bytes = _DEFAULT_SCRATCH[0].data_ptr(), _DEFAULT_SCRATCH[1]
+
+
+def set_default_scratch(tensor):
+    """Attach `tensor` (zero-filled uint8 device memory of CONV_SCRATCH_BYTES, or None) to every ConvDesc created
+    from now on that names no scratch buffer of its own (tests and micro-benchmarks; the engine passes its own)."""
+    global _DEFAULT_SCRATCH
+    _DEFAULT_SCRATCH = None if tensor is None else (tensor, tensor.numel() * tensor.element_size())
+
+
+CONV_SCRATCH_BYTES = 4096 + 256 * 256 * 256 * 4      # VAMD_CONV_SCRATCH_BYTES
 
 
 class RepackItem(C.Structure):

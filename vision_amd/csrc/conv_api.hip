@@ -22,6 +22,10 @@ int conv_geom(const vamd_conv_desc* d, ConvGeom* g, const char* who) {
     g->Ho = (g->He + 2 * g->pad - g->k) / g->stride + 1;
     g->Wo = (g->We + 2 * g->pad - g->k) / g->stride + 1;
     g->M = (int64_t)g->B * g->Ho * g->Wo;
+    g->scratch = d->scratch;
+    g->scratch_bytes = d->scratch ? (size_t)d->scratch_bytes : 0;
+    if (d->scratch && ((uintptr_t)d->scratch % 256 != 0))
+        return fail(VAMD_EINVAL, "%s: scratch must be 256-byte aligned", who);
     const int64_t esz = d->dtype == VAMD_BF16 ? 2 : 4;
     const int64_t in_bytes = (int64_t)g->B * g->H * g->W * g->Cin * esz;
     const int64_t out_bytes = g->M * g->Cout * esz;

@@ -25,274 +25,11 @@
 #error "VAMD_ABLATE variants compute wrong results: build them with `build_ext.py --variant NAME -DVAMD_ABLATE=n` (a separately named library), never into libvision_amd.so"
 #endif
 
+#include "conv_nt_common.h"
+
 namespace vamd {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
-
-#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-struct FastDiv {
-    uint32_t magic, shift;
-};
-static FastDiv make_fastdiv(uint32_t d) {       // exact for numerators < 2^26
-    uint32_t l = 0;
-    while ((1u << l) < d) ++l;
-    FastDiv f;
-    f.shift = 26 + l;
-    f.magic = (uint32_t)(((1ull << f.shift) + d - 1) / d);
-    return f;
-}
-__device__ __forceinline__ uint32_t fdiv(uint32_t m, FastDiv d) {
-    return (uint32_t)(((uint64_t)m * d.magic) >> d.shift);
-}
-
-// How GEMM row m (an output pixel) and a filter tap address the stored input tensor.
-struct Gather {
-    int Hin, Win, Cin;     // stored input extents and channels
-    int ldx;               // elements between consecutive stored pixels (Cin unless rows are padded)
-    int He, We;            // valid range of the tap coordinate u = ho*stride + r - pad
-    int Ho, Wo;            // extents that m enumerates
-    int k, stride, pad;    // pad: rows; padw: columns (equal except for the classes of an upsampling forward)
-    int padw;
-    int shift;             // 1: stored row = u >> 1 (nearest 2x upsample folded into the gather)
-    int M, Ktot;           // rows, and (tap rows)*(tap columns)*Cin
-    FastDiv div_howo, div_wo;
-    // Sub-filter views (stride-2 input gradient, one launch per output parity class):
-    int kr, ks;            // tap rows and columns (k, k for a square filter); Ktot = kr * ks * Cin
-    int wr0, ws0, wstep, wk;   // tap (tr, ts) reads filter tap (wr0 + wstep*tr, ws0 + wstep*ts) of a wk x wk filter
-    int oH, oW, ostep, oph, opw;   // ostep = 2: row (b, ho, wo) is written to pixel (b, 2*ho + oph, 2*wo + opw) of an oH x oW image    // Second source (gather mode 2): after the kr*ks taps the reduction runs on over Cin2 channels of the
-    // pixel itself in x2 [M][Cin2] against w2 [N][Cin2] - a 1x1 convolution of another tensor summed into
-    // the same accumulators (the shortcut of a ResNetBlock inside its conv2).  Ktot includes Cin2.
-    const void* x2;
-    const void* w2;
-    int Cin2;
-};
-
-struct Epilogue {
-    const float* bias;     // [N]
-    const float* temb;     // [B][N]
-    const void* res;       // [M][N] in T
-    const void* res2;
-    float alpha;
-    int out_f32;           // store fp32 instead of T
-    float* stats;          // [row tiles][N][2]: per row tile, column sums of the stored y and y*y (or NULL)
-};
-
-// Up to four convolutions of one layer in one launch (the output-parity classes of a stride-2 input
-// gradient): the grid is cut into per-class block ranges, a workgroup takes the gather, the tile
-// count, the filter offset and the statistics offset of its class and then runs as usual.
-struct ClassSet {
-    int ncls;                  // <= 1: a plain launch, the kernel's own arguments apply
-    int first_block[5];        // class c owns blocks [first_block[c], first_block[c+1])
-    int m_tiles[4];
-    int64_t w_off[4];          // elements added to the filter pointer
-    int64_t stats_off[4];      // floats added to the statistics pointer
-    Gather g[4];
-};
-
-// Branch-free pointer select: keeps the staging code of a K-step in one basic block, so that the
-// scheduler may place it between MFMAs.
-template <typename T> __device__ __forceinline__ const T* pick_ptr(bool ok, const T* a, const T* b) {
-    const uint64_t m = 0ull - (uint64_t)ok;
-    return reinterpret_cast<const T*>(((uint64_t)a & m) | ((uint64_t)b & ~m));
-}
-
-// Direct-to-LDS 16-byte load through a buffer resource: the base pointer lives in scalar registers,
-// a lane supplies a 32-bit byte offset, and an offset at or beyond the resource's size (kNoLoad)
-// makes the hardware write zeros - padding taps and rows past the tensor cost one select, no
-// 64-bit pointer arithmetic.  Tensors are < 2 GiB (checked on the host).
-constexpr uint32_t kNoLoad = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFF0, 0x00020000);
-}
-__device__ __forceinline__ void load16_lds(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, bool ok, unsigned char* lds) {
-#if VAMD_ABLATE == 9        // every load hits the same 1 KiB: the address arithmetic stays, the memory traffic goes
-    byte_off = (byte_off & 0x3f0u);
-#endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LPTR(lds), 16, (int)(ok ? byte_off : kNoLoad), 0, 0, 0);
-}
-
-template <typename T> struct ElemTraits;
-template <> struct ElemTraits<bf16_t> { static constexpr int PIECE = 8; typedef bf16x8_t Frag; };   // elements per 16 bytes
-template <> struct ElemTraits<float> { static constexpr int PIECE = 4; typedef f32x4_t Frag; };
-
-constexpr int kBM = 128;
-constexpr int kRowBytes = 128;                   // reduction bytes per K-step
-
-__device__ __forceinline__ int xcd_remap(int id, int nwg) {
-    // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous id range
-    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-}
-
-// Epilogue of the persistent kernels for the four pixel tiles a lane holds (rows m_first + 16*i, channels
-// nb .. nb + 4*NT - 1): y = alpha*acc + temb[image] + res + res2, rounded to T, stored, and (STATS) added
-// to the lane's per-channel sums.  Every load of a term is issued before the first use of any of them
-// and before any store: written row by row, the loads of a row could not move above the previous
-// row's store (the pointers may alias as far as the compiler knows), so a tile paid one memory
-// latency per 16-byte piece instead of one per term.  The sums land in the accumulators, which are
-// re-initialised for the next tile anyway; the order of the additions is temb, res, res2.
-// Core: the four rows are given by the element offset of the lane's first channel (offs), the image
-// each belongs to (bimg, for the time embedding; ascending) and a validity flag.
-template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT>
-__device__ __forceinline__ void epilogue_rows_at(f32x4_t (&acc)[NT][4], float* s1, float* s2,
-                                                 const float* temb, const void* res, const void* res2, float alpha,
-                                                 int out_f32, void* yout, int N, int ldc, const int64_t (&offs)[4],
-                                                 const uint32_t (&bimg)[4], const bool (&valid)[4], int nb) {
-    static_assert(C0 % 8 == 0 && CW % 8 == 0 && C0 + CW <= 4 * NT, "whole 16-byte pieces of the lane's channels");
-    constexpr int CH = 16 / (int)sizeof(T);               // channels per 16-byte piece of T: 8 (bf16) or 4
-    constexpr int NP = CW / CH;                           // pieces per row and lane
-    constexpr int J0 = C0 / 4, NJ = CW / 4;               // accumulator (channel tile) range
-    if (out_f32) {                                     // fp32 outputs of a bf16 product (attention scores)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (!valid[i]) continue;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nb + 4 * j;
-                // a trailing partial group is written whole: its extra columns are exact zeros
-                // (their filter rows were never loaded) and ldc leaves room for them
-                if (n < N && n + 4 <= ldc)
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yout) + offs[i] + 4 * j) =
-                        make_float4(acc[J0 + j][i][0] * alpha, acc[J0 + j][i][1] * alpha, acc[J0 + j][i][2] * alpha,
-                                    acc[J0 + j][i][3] * alpha);
-            }
-        }
-        return;
-    }
-    bool piece_ok[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) piece_ok[p] = nb + p * CH < N && nb + p * CH + CH <= ldc;
-    const T* r1 = reinterpret_cast<const T*>(res ? res : res2);
-    const T* r2 = reinterpret_cast<const T*>(res ? res2 : nullptr);
-    // ---- issue: time embedding of the first row's image, first residual
-    float tv[CW];
-#pragma unroll
-    for (int e = 0; e < CW; ++e) tv[e] = 0.f;
-    if (temb && valid[0]) {                            // rows ascend: an invalid first row means no valid row
-        const float* tp = temb + (int64_t)bimg[0] * N + nb;
-#pragma unroll
-        for (int e = 0; e < CW; e += 4) {
-            if (nb + e + 4 <= N) {
-                const float4 t4 = *reinterpret_cast<const float4*>(tp + e);
-                tv[e] = t4.x; tv[e + 1] = t4.y; tv[e + 2] = t4.z; tv[e + 3] = t4.w;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tv[e + r] = nb + e + r < N ? tp[e + r] : 0.f;
-            }
-        }
-    }
-    Vec16<T> rv[4][NP];
-    if (r1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-                if (valid[i] && piece_ok[p]) rv[i][p] = *reinterpret_cast<const Vec16<T>*>(r1 + offs[i] + p * CH);
-    }
-    // ---- use
-    if (alpha != 1.f) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[J0 + j][i] *= alpha;
-    }
-    if (temb) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (bimg[i] == bimg[0]) {
-#pragma unroll
-                for (int e = 0; e < CW; ++e) acc[J0 + (e >> 2)][i][e & 3] += tv[e];
-            } else if (valid[i]) {                        // the tile crosses into the next image: rare
-                const float* tp = temb + (int64_t)bimg[i] * N + nb;
-#pragma unroll
-                for (int e = 0; e < CW; ++e)
-                    if (nb + e < N) acc[J0 + (e >> 2)][i][e & 3] += tp[e];
-            }
-        }
-    }
-    if (r1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-                if (valid[i] && piece_ok[p]) {
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) acc[J0 + ((p * CH + e) >> 2)][i][e & 3] += to_f(rv[i][p].v[e]);
-                }
-    }
-    if (r2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-                if (valid[i] && piece_ok[p]) rv[i][p] = *reinterpret_cast<const Vec16<T>*>(r2 + offs[i] + p * CH);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-                if (valid[i] && piece_ok[p]) {
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) acc[J0 + ((p * CH + e) >> 2)][i][e & 3] += to_f(rv[i][p].v[e]);
-                }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (!valid[i]) continue;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            if (!piece_ok[p]) continue;
-            Vec16<T> ov;
-#pragma unroll
-            for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(acc[J0 + ((p * CH + e) >> 2)][i][e & 3]);
-            *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + offs[i] + p * CH) = ov;
-            if constexpr (STATS) {                        // statistics of the rounded values a later pass would read
-#pragma unroll
-                for (int e = 0; e < CH; ++e) {
-                    const float q = to_f(ov.v[e]);
-                    s1[p * CH + e] += q;
-                    s2[p * CH + e] = fmaf(q, q, s2[p * CH + e]);
-                }
-            }
-        }
-    }
-}
-
-// The same for rows m_first + 16*i of the GEMM (with the output scatter of a parity class, if any).
-template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT>
-__device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[NT][4], float* s1, float* s2, const Gather& gp,
-                                              const float* temb, const void* res, const void* res2, float alpha,
-                                              int out_f32, void* yout, int N, int ldc, int64_t zoff,
-                                              uint32_t m_first, int nb) {
-    nb += C0;
-    int64_t offs[4];
-    uint32_t bimg[4];
-    bool valid[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t m = m_first + 16 * i;
-        valid[i] = m < (uint32_t)gp.M;
-        bimg[i] = 0;
-        int64_t orow = m;
-        if (gp.ostep || temb) {
-            bimg[i] = fdiv(m, gp.div_howo);
-            if (gp.ostep) {
-                const uint32_t rem = m - bimg[i] * (uint32_t)(gp.Ho * gp.Wo);
-                const uint32_t ho = fdiv(rem, gp.div_wo);
-                const uint32_t wo = rem - ho * gp.Wo;
-                orow = ((int64_t)bimg[i] * gp.oH + ho * gp.ostep + gp.oph) * gp.oW + wo * gp.ostep + gp.opw;
-            }
-        }
-        offs[i] = zoff + orow * ldc + nb;
-    }
-    epilogue_rows_at<T, NT, STATS, C0, CW>(acc, s1, s2, temb, res, res2, alpha, out_f32, yout, N, ldc, offs, bimg, valid, nb);
-}
 
 template <typename T, int BN, bool UP>
 __global__ void __launch_bounds__(256, 2)
@@ -2168,6 +1905,12 @@ static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw
             return launch_c64_halo<3, 3>(ha, (const bf16_t*)x, (const bf16_t*)w, ep, y, 2.0 * gp.M * N * 576, st);
         }
     }
+    if constexpr (sizeof(T) == 2) {
+        if (!classes && nt8_applicable(gp, N, ldw, ldc, ep, batch)) {
+            const double fl = 2.0 * gp.M * N * gp.Ktot;
+            return launch_nt8(gp, x, w, N, ldw, ldc, ep, y, take_flops(fl), fl, st);
+        }
+    }
     if (classes) {                                        // class sets: stride-1 gathers without upsampling
         if (N <= 64) return launch_nt<T, 64, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
         return launch_nt<T, 128, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
@@ -2207,6 +1950,11 @@ int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype) {
         int pwl, tw, th, nt;                              // as run_nt picks the resident-filter kernel
         if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return c64_halo_blocks(nt, g.Cout / 64) / (g.Cout / 64);
     }
+    if (dtype == VAMD_BF16) {                             // as run_nt picks the ping-pong kernel
+        const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
+        const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
+        if (nt8_applicable(gp, g.Cout, gp.Ktot, g.Cout, ep, 1)) return nt8_stats_parts(gp, g.Cout, ep);
+    }
     if (dtype == VAMD_BF16 && nt_wide256(g.Cout, g.M, 1, 2, g.k * g.k * g.Cin, g.up != 0)) return ntp_row_groups((int)((g.M + 255) / 256), g.Cout / 256, 1);
     const int BN = g.Cout <= 64 ? 64 : 128;               // as run_nt picks
     const int n_tiles = (g.Cout + BN - 1) / BN;
@@ -2217,7 +1965,7 @@ int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype) {
 int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
                   const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st) {
     Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
-    Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats};
+    Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats, (unsigned char*)g.scratch, g.scratch_bytes};
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
     return run_nt<float>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
 }
@@ -2232,6 +1980,11 @@ bool conv_fwd_short_mfma_supported(const ConvGeom& g, int dtype, int Cin2) {
     if (dtype == VAMD_BF16 && g.Cin == 64 && (g.Cout == 64 || g.Cout == 128) && g.k == 3 && g.pad == 1) {
         int pwl, tw, th, nt;                              // the resident-filter kernel serves the plain conv: keep the two launches
         if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return false;
+    }
+    if (dtype == VAMD_BF16) {                             // likewise where the ping-pong kernel serves the plain conv
+        const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
+        const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
+        if (nt8_applicable(gp, g.Cout, gp.Ktot, g.Cout, ep, 1)) return false;
     }
     return nt_shape_ok(g.Cin, g.Cout, g.M, dtype);
 }
@@ -2425,7 +2178,7 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
         out = workspace;
         res = nullptr;
     }
-    Epilogue ep{nullptr, nullptr, res, nullptr, 1.0f, 0, nullptr};
+    Epilogue ep{nullptr, nullptr, res, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
     int rc = dtype == VAMD_BF16 ? run_nt<bf16_t>(gp, dy, wt, g.Cin, gp.Ktot, g.Cin, ep, out, 1, 0, 0, 0, st)
                                 : run_nt<float>(gp, dy, wt, g.Cin, gp.Ktot, g.Cin, ep, out, 1, 0, 0, 0, st);
     if (rc) return rc;
@@ -2455,7 +2208,7 @@ int conv_dgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void
                         hipStream_t st) {
     Gather gp = make_gather(g.Ho, g.Wo, g.Cout, g.Ho, g.Wo, g.H, g.W, 4, 2, 1, 0, (int64_t)g.B * g.H * g.W);
     t_nominal_flops = 2.0 * g.M * g.Cout * 9.0 * g.Cin;
-    Epilogue ep{nullptr, nullptr, add, nullptr, 1.0f, 0, nullptr};
+    Epilogue ep{nullptr, nullptr, add, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, dy, w4, g.Cin, gp.Ktot, g.Cin, ep, dx, 1, 0, 0, 0, st);
     return run_nt<float>(gp, dy, w4, g.Cin, gp.Ktot, g.Cin, ep, dx, 1, 0, 0, 0, st);
 }

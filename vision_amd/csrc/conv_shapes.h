@@ -10,6 +10,8 @@ struct ConvGeom {
     int He, We;               // effective input extents (after the optional nearest 2x upsample)
     int Ho, Wo;               // output extents
     int64_t M;                // B * Ho * Wo output pixels
+    void* scratch;            // the descriptor's optional scratch buffer
+    size_t scratch_bytes;
 };
 
 // Validates a vamd_conv_desc and fills `g`.  Returns 0 or a negative status (message set).

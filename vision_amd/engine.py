@@ -66,6 +66,8 @@ class _Conv:
         if d is None:
             d = ConvDesc(B, H, W, self.cin, self.cout, self.k, self.stride, self.pad, int(self.up),
                          self.eng.dt, self.eng.algo)
+            if self.eng.scratch is not None:      # lets the wide kernels split tiles between workgroups
+                d.scratch, d.scratch_bytes = self.eng.scratch.data_ptr(), self.eng.scratch.numel()
             self._descs[key] = d
         return d
 
@@ -483,6 +485,10 @@ class Engine:
         self.device = params[0][1].device
         self.plan, self.dtype, self.algo = plan, dtype, algo
         self.stats_for: Dict[int, tuple] = {}      # output data_ptr -> (partial sums, parts) left by a conv epilogue
+        # zero-filled once, then owned by the kernels (flags and partial sums of tiles split between workgroups)
+        self.scratch = None
+        if dtype == torch.bfloat16 and os.environ.get("VAMD_NT8_STREAMK", "0") != "0":
+            self.scratch = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=self.device)
         self.dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}[dtype]
 
         # one flat fp32 arena for parameters and one for gradients; every nn.Parameter becomes a view
