@@ -343,6 +343,26 @@ int vamd_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
                const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                int step, float grad_scale, void* stream);
 
+/* ---- latent diffusion first stage: vector-quantisation codebook lookup ------------------------------- */
+/* Replaces VQBlock.forward (reference models/vqvaeunet.py:115-146; the same block in models/vqvae.py:13-55).
+ * z: M = images * HW latent rows of D features, fp32, channels-first when nchw != 0 ([B, D, H, W], what
+ * VQBlock.forward receives) or channels-last rows; codebook: [K, D] (nn.Embedding weight, vqvaeunet.py:112).
+ * indices[M]: argmin_k of (|z|^2 + |e_k|^2) - 2 z.e_k evaluated in fp32 with every sum taken over d = 0..D-1 by
+ * fused multiply-adds (vqvaeunet.py:121-126); equal distances resolve to the smallest index, a NaN distance wins.
+ * out (layout of z): z + (e[index] - z), the straight-through value of vqvaeunet.py:144.
+ * loss[0] = mse * beta + mse, loss[1] = mse = mean((e[index] - z)^2)  (vqvaeunet.py:138-141).
+ * workspace: vamd_vq_workspace(M) bytes of device memory. */
+size_t vamd_vq_workspace(int64_t M);
+int vamd_vq_forward(const float* z, const float* codebook, int64_t M, int D, int K, int HW, int nchw, float beta,
+                    int64_t* indices, float* out, float* loss, void* workspace, size_t workspace_bytes, void* stream);
+/* Gradients of the two outputs of vamd_vq_forward as autograd defines them for vqvaeunet.py:138-144:
+ * dz = g_out + g_loss * beta * 2 (z - e[index]) / (M D); dcodebook[k] = g_loss * 2 / (M D) * sum over the rows with
+ * index k of (e[k] - z).  g_out (layout of z) and g_loss (one device float) may be NULL (= zero); dz or dcodebook
+ * may be NULL (not wanted).  D <= 1024.  Rows of one code are added in ascending order: bit-reproducible. */
+int vamd_vq_backward(const float* z, const float* codebook, const int64_t* indices, const float* g_out,
+                     const float* g_loss, int64_t M, int D, int K, int HW, int nchw, float beta, float* dz,
+                     float* dcodebook, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

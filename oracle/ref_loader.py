@@ -80,3 +80,23 @@ def load_reference_ddpm():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_reference_vqblock():
+    """The reference module models/vqvaeunet.py (its `VQBlock`, models/vqvaeunet.py:104-146).  The file does
+    `from . import Custumnn` (models/vqvaeunet.py:10), so it is executed as a submodule of an empty stand-in
+    package whose search path is the reference's models/ directory -- models/__init__.py itself (which imports
+    every model family) is not run."""
+    if not reference_available():
+        raise FileNotFoundError(f"reference not mounted at {REFERENCE_ROOT}")
+    _install_stubs()
+    pkg_dir = os.path.join(REFERENCE_ROOT, "models")
+    if "ref_models" not in sys.modules:
+        pkg = types.ModuleType("ref_models")
+        pkg.__path__ = [pkg_dir]
+        sys.modules["ref_models"] = pkg
+    spec = importlib.util.spec_from_file_location("ref_models.vqvaeunet", os.path.join(pkg_dir, "vqvaeunet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_models.vqvaeunet"] = mod
+    spec.loader.exec_module(mod)
+    return mod
