@@ -6,6 +6,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/collect
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+python -c "import sys; sys.path.insert(0, '$ROOT'); from vision_amd import _lib; print(_lib.source_hash())" > $OUT/source_hash.txt
+(cd $ROOT && timeout -k 10 300 python bench.py > $OUT/bench_butterfly.json 2> $OUT/bench_butterfly.err) && echo "butterfly done"
+(cd $ROOT && timeout -k 10 300 python bench.py --preset flowers --no-cpu-baseline > $OUT/bench_flowers.json 2> $OUT/bench_flowers.err) && echo "flowers done"
+(cd $ROOT && timeout -k 10 400 python bench.py --preset ffhq --no-cpu-baseline --steps 5 --warmup 2 > $OUT/bench_ffhq.json 2> $OUT/bench_ffhq.err) && echo "ffhq done"
 BENCH="python $ROOT/bench.py --no-cpu-baseline --no-sampling"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 10 --warmup 3 > $OUT/trace.log 2>&1
 echo "trace done"

@@ -1,5 +1,7 @@
 """Turns gpurun_out/collect (written by profiles/collect.sh) into the committed summaries:
-r1_train_step_kernel_stats.csv, r1_train_step_bench_line.json, r1_pmc_tcc_traffic.csv, r1_pmc_sq_summary.csv."""
+r2_train_step_kernel_stats.csv, r2_train_step_bench_line.json, r2_bench_lines.json (the three presets without a
+profiler attached), r2_pmc_tcc_traffic.csv (first line: hash of the kernel sources it was taken with) and
+r2_pmc_sq_summary.csv."""
 import collections
 import csv
 import glob
@@ -8,6 +10,7 @@ import shutil
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROUND = "r2"
 SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "gpurun_out", "collect")
 
 
@@ -26,13 +29,15 @@ def counters(sub):
     return agg, {k: len(v) for k, v in launches.items()}
 
 
-shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(HERE, "r1_train_step_kernel_stats.csv"))
+shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(HERE, ROUND + "_train_step_kernel_stats.csv"))
 line = [ln for ln in open(os.path.join(SRC, "trace.log")) if ln.startswith("{")][-1]
-open(os.path.join(HERE, "r1_train_step_bench_line.json"), "w").write(line)
+open(os.path.join(HERE, ROUND + "_train_step_bench_line.json"), "w").write(line)
 
 fetch, nf = counters("fetch")
 write, _ = counters("write")
-with open(os.path.join(HERE, "r1_pmc_tcc_traffic.csv"), "w", newline="") as f:
+stamp = open(os.path.join(SRC, "source_hash.txt")).read().strip()
+with open(os.path.join(HERE, ROUND + "_pmc_tcc_traffic.csv"), "w", newline="") as f:
+    f.write(f"# kernel_source_sha256_16={stamp}\n")
     w = csv.writer(f)
     w.writerow(["kernel", "launches", "FETCH_SIZE_KB_sum", "WRITE_SIZE_KB_sum", "hbm_bytes_per_launch(2*FETCH+WRITE)*1024"])
     rows = []
@@ -44,9 +49,12 @@ with open(os.path.join(HERE, "r1_pmc_tcc_traffic.csv"), "w", newline="") as f:
 
 sq, ns = counters("sq")
 names = sorted({c for v in sq.values() for c in v})
-with open(os.path.join(HERE, "r1_pmc_sq_summary.csv"), "w", newline="") as f:
+with open(os.path.join(HERE, ROUND + "_pmc_sq_summary.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "launches"] + names)
     for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
         w.writerow([k, ns[k]] + [round(v.get(c, 0.0)) for c in names])
+with open(os.path.join(HERE, ROUND + "_bench_lines.json"), "w") as f:
+    for preset in ("butterfly", "flowers", "ffhq"):
+        f.write([ln for ln in open(os.path.join(SRC, f"bench_{preset}.json")) if ln.startswith("{")][-1])
 print("wrote summaries from", SRC)
