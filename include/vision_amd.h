@@ -266,6 +266,15 @@ int vamd_bmm_tn(const void* A, const void* Bm, void* C, int batch, int M, int N,
                 int ldb, int ldc, float alpha, int dtype, int algo, void* stream);
 /* y[b][h][w][c] = sum of the 2x2 block of x [B][2H][2W][C]: gradient of nn.Upsample (models/ddpm.py:33). */
 int vamd_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+/* Resampling blocks built without a convolution (with_conv: false): nn.AvgPool2d((2, 2)) (reference
+ * models/ddpm.py:21) and bare nn.Upsample(scale_factor=2, mode='nearest') (models/ddpm.py:33), channels-last.
+ * pool:   x [B][H][W][C] -> y [B][H/2][W/2][C] = scale * (2x2 block sum) + add   (add in y's shape, or NULL)
+ * unpool: x [B][Hs][Ws][C] -> y [B][H][W][C], H/2 == Hs, W/2 == Ws: y = scale * x[h/2][w/2] + add; a trailing odd row or
+ *         column of y (dropped by the pooling this transposes) receives add alone.
+ * AvgPool2d forward = pool(0.25) and its input gradient = unpool(0.25); Upsample forward = unpool(1), gradient = pool(1). */
+int vamd_pool2x2(const void* x, const void* add, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
+int vamd_unpool2x2(const void* x, const void* add, void* y, int B, int Hs, int Ws, int C, int H, int W, float scale, int dtype,
+                   void* stream);
 /* x [batch][R][C] -> y [batch][C][ldy] (ldy >= R; padding columns are left untouched). */
 int vamd_transpose(const void* x, void* y, int batch, int R, int C, int ldy, int dtype, void* stream);
 /* Row softmax over the first `cols` entries of rows of stride ld (F.softmax, models/ddpm.py:118)

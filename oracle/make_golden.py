@@ -34,8 +34,12 @@ CONFIGS = {
     # t0 with dropout 0.1 in the two Middle blocks, masks recorded.
     "t0_drop": dict(BASE, h_dims=[3, 32, 32], down_index=[0, 1, 1], attn_res=[8], patch_size=16,
                     dropout=0.1, latent_dim=[3, 16, 16]),
+    # t0 built without resampling convolutions: AvgPool2d((2, 2)) down, bare nearest Upsample up
+    # (reference models/ddpm.py:21,33).
+    "t0_pool": dict(BASE, h_dims=[3, 32, 32], down_index=[0, 1, 1], attn_res=[8], patch_size=16,
+                    dropout=0.0, latent_dim=[3, 16, 16], with_conv=False),
 }
-BATCH = {"t0": 4, "t1": 3, "t0_drop": 4}
+BATCH = {"t0": 4, "t1": 3, "t0_drop": 4, "t0_pool": 4}
 
 
 class _DropoutRecorder:

@@ -42,7 +42,7 @@ def noise_keys(tensors):
             if k.startswith("grad/") and k.endswith((".block1.0.2.bias", ".linear_temb.bias", ".k_proj.bias"))}
 
 
-@pytest.fixture(scope="session", params=["t0", "t1", "t0_drop"])
+@pytest.fixture(scope="session", params=["t0", "t1", "t0_drop", "t0_pool"])
 def golden(request):
     return (request.param,) + load_golden(request.param)
 

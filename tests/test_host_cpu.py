@@ -57,7 +57,7 @@ def test_version_and_error_string_without_gpu():
     assert _lib.lib.vamd_last_error()
 
 
-@pytest.mark.parametrize("name", ["t0", "t1", "t0_drop"])
+@pytest.mark.parametrize("name", ["t0", "t1", "t0_drop", "t0_pool"])
 def test_seeded_init_and_state_dict_match_reference(name):
     """torch.manual_seed(seed) + construction consumes the RNG exactly like the reference's
     DDPMModel.__init__ (models/ddpm.py:236-262): same keys, same order, same bits."""

@@ -744,3 +744,46 @@ def test_linear_fwd_multi_matches_single():
         assert torch.equal(y, one)
         ref = F.leaky_relu(x.double().cpu(), 0.01) @ W.double().cpu().T + (b.double().cpu() if b is not None else 0.0)
         assert relerr(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (3, 7, 9, 64), (2, 6, 10, 3), (1, 224, 224, 64)], ids=lambda s: "x".join(map(str, s)))
+def test_pool_and_unpool_2x2(shape, dts):
+    """nn.AvgPool2d((2, 2)) and nn.Upsample(scale_factor=2, mode='nearest') of the resampling blocks built without a
+    convolution (reference models/ddpm.py:21,33), forward and gradient, each with the fused addend, against torch
+    on the CPU in fp64.  Odd extents: the pooling drops the last row / column, its gradient leaves them zero."""
+    B, H, W, Cc = shape
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(sum(shape))
+    x, x64 = rnd((B, Cc, H, W), tdt, gen)
+    Ho, Wo = H // 2, W // 2
+    add, add64 = rnd((B, Cc, Ho, Wo), tdt, gen)
+    dy, dy64 = rnd((B, Cc, Ho, Wo), tdt, gen)
+    addx, addx64 = rnd((B, Cc, H, W), tdt, gen)
+    tol = 1e-6 if dts == "f32" else 4e-3
+    x64 = x64.requires_grad_(True)
+    y64 = F.avg_pool2d(x64, (2, 2))
+    (gx,) = torch.autograd.grad(y64, [x64], dy64)
+    xn, addn, dyn, addxn = nhwc(x), nhwc(add), nhwc(dy), nhwc(addx)
+    y = torch.full((B, Ho, Wo, Cc), 7.0, dtype=tdt, device=DEV)
+    call("vamd_pool2x2", P(xn), P(addn), P(y), B, H, W, Cc, 0.25, dt, S())
+    assert relerr(y.permute(0, 3, 1, 2), y64.detach() + add64) < tol
+    call("vamd_pool2x2", P(xn), None, P(y), B, H, W, Cc, 0.25, dt, S())
+    assert relerr(y.permute(0, 3, 1, 2), y64.detach()) < tol
+    dx = torch.full((B, H, W, Cc), 7.0, dtype=tdt, device=DEV)
+    call("vamd_unpool2x2", P(dyn), P(addxn), P(dx), B, Ho, Wo, Cc, H, W, 0.25, dt, S())
+    assert relerr(dx.permute(0, 3, 1, 2), gx + addx64) < tol
+    call("vamd_unpool2x2", P(dyn), None, P(dx), B, Ho, Wo, Cc, H, W, 0.25, dt, S())
+    assert relerr(dx.permute(0, 3, 1, 2), gx) < tol
+    # upsampling: forward = unpool(1) to exactly twice the size, gradient = pool(1)
+    s, s64 = rnd((B, Cc, Ho, Wo), tdt, gen)
+    s64 = s64.requires_grad_(True)
+    u64 = F.interpolate(s64, scale_factor=2, mode="nearest")
+    du, du64 = rnd(tuple(u64.shape), tdt, gen)
+    (gs,) = torch.autograd.grad(u64, [s64], du64)
+    u = torch.full((B, 2 * Ho, 2 * Wo, Cc), 7.0, dtype=tdt, device=DEV)
+    call("vamd_unpool2x2", P(nhwc(s)), None, P(u), B, Ho, Wo, Cc, 2 * Ho, 2 * Wo, 1.0, dt, S())
+    assert torch.equal(u.permute(0, 3, 1, 2).cpu().double(), u64.detach())
+    ds = torch.full((B, Ho, Wo, Cc), 7.0, dtype=tdt, device=DEV)
+    call("vamd_pool2x2", P(nhwc(du)), P(addn), P(ds), B, 2 * Ho, 2 * Wo, Cc, 1.0, dt, S())
+    assert relerr(ds.permute(0, 3, 1, 2), gs + add64) < tol

@@ -110,6 +110,8 @@ SIGNATURES = {
     "vamd_bmm_nt": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p]),
     "vamd_bmm_tn": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "vamd_sumpool2x2": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_pool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "vamd_unpool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "vamd_transpose": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vamd_softmax_rows": (_i, [_p, _p, _l, _i, _i, _i, _p]),
     "vamd_softmax_rows_bwd": (_i, [_p, _p, _p, _l, _i, _i, _f, _i, _p]),

@@ -549,6 +549,78 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwk, float* __rest
     }
 }
 
+// 2x2 pooling and its transpose on channels-last tensors (the resampling blocks built without a convolution,
+// reference models/ddpm.py:21 nn.AvgPool2d((2, 2)) and :33 nn.Upsample(scale_factor=2, mode='nearest')):
+//   pool:   y[b][h][w][c] = scale * (sum of x[b][2h..2h+1][2w..2w+1][c]) + add      (H/2 x W/2, floor)
+//   unpool: y[b][h][w][c] = scale * x[b][h/2][w/2][c] + add  for h < 2*Hs, w < 2*Ws, else add alone (or 0)
+// AvgPool forward = pool(0.25), its gradient = unpool(0.25); nearest upsampling = unpool(1), its gradient = pool(1).
+template <typename T, int VEC>
+__global__ void pool2x2_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ y, int B, int H, int W,
+                               int C, float scale) {
+    const int Ho = H / 2, Wo = W / 2, CV = C / VEC;
+    const int64_t total = (int64_t)B * Ho * Wo * CV;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % CV);
+        int64_t p = idx / CV;
+        const int w = (int)(p % Wo); p /= Wo;
+        const int h = (int)(p % Ho);
+        const int64_t b = p / Ho;
+        const T* s = x + ((b * H + 2 * h) * W + 2 * w) * (int64_t)C + cv * VEC;
+        const int64_t row = (int64_t)W * C;
+        T v00[VEC], v01[VEC], v10[VEC], v11[VEC], av[VEC], ov[VEC];
+        if (VEC > 1) {
+            *reinterpret_cast<Vec16<T>*>(v00) = *reinterpret_cast<const Vec16<T>*>(s);
+            *reinterpret_cast<Vec16<T>*>(v01) = *reinterpret_cast<const Vec16<T>*>(s + C);
+            *reinterpret_cast<Vec16<T>*>(v10) = *reinterpret_cast<const Vec16<T>*>(s + row);
+            *reinterpret_cast<Vec16<T>*>(v11) = *reinterpret_cast<const Vec16<T>*>(s + row + C);
+            if (add) *reinterpret_cast<Vec16<T>*>(av) = *reinterpret_cast<const Vec16<T>*>(add + idx * VEC);
+        } else {
+            v00[0] = s[0]; v01[0] = s[C]; v10[0] = s[row]; v11[0] = s[row + C];
+            if (add) av[0] = add[idx];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float f = ((to_f(v00[j]) + to_f(v01[j])) + to_f(v10[j]) + to_f(v11[j])) * scale;
+            if (add) f += to_f(av[j]);
+            ov[j] = from_f<T>(f);
+        }
+        if (VEC > 1) *reinterpret_cast<Vec16<T>*>(y + idx * VEC) = *reinterpret_cast<Vec16<T>*>(ov);
+        else y[idx] = ov[0];
+    }
+}
+
+template <typename T, int VEC>
+__global__ void unpool2x2_kernel(const T* __restrict__ x, const T* __restrict__ add, T* __restrict__ y, int B, int Hs, int Ws,
+                                 int C, int H, int W, float scale) {
+    const int CV = C / VEC;
+    const int64_t total = (int64_t)B * H * W * CV;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % CV);
+        int64_t p = idx / CV;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int64_t b = p / H;
+        const bool in = (h >> 1) < Hs && (w >> 1) < Ws;
+        T xv[VEC], av[VEC], ov[VEC];
+        if (VEC > 1) {
+            if (in) *reinterpret_cast<Vec16<T>*>(xv) =
+                *reinterpret_cast<const Vec16<T>*>(x + ((b * Hs + (h >> 1)) * Ws + (w >> 1)) * (int64_t)C + cv * VEC);
+            if (add) *reinterpret_cast<Vec16<T>*>(av) = *reinterpret_cast<const Vec16<T>*>(add + idx * VEC);
+        } else {
+            if (in) xv[0] = x[((b * Hs + (h >> 1)) * Ws + (w >> 1)) * (int64_t)C + cv];
+            if (add) av[0] = add[idx];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float f = in ? to_f(xv[j]) * scale : 0.f;
+            if (add) f += to_f(av[j]);
+            ov[j] = from_f<T>(f);
+        }
+        if (VEC > 1) *reinterpret_cast<Vec16<T>*>(y + idx * VEC) = *reinterpret_cast<Vec16<T>*>(ov);
+        else y[idx] = ov[0];
+    }
+}
+
 }  // namespace vamd
 
 using namespace vamd;
@@ -720,6 +792,42 @@ int vamd_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* 
                            as_stream(stream), (const T*)a, (const T*)b, (T*)y, nvec, n);
     });
     VAMD_LAUNCH_OK("vamd_add");
+    return 0;
+}
+
+int vamd_pool2x2(const void* x, const void* add, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream) {
+    VAMD_REQUIRE(x && y && B > 0 && H >= 2 && W >= 2 && C > 0, "vamd_pool2x2: bad argument");
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
+    VAMD_DISPATCH(dtype, "vamd_pool2x2", {
+        constexpr int V = Vec16<T>::N;
+        const bool vec = C % V == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)add % 16 == 0;
+        if (vec)
+            hipLaunchKernelGGL((pool2x2_kernel<T, V>), dim3(grid_for(total / V, 256, 65536)), dim3(256), 0, as_stream(stream),
+                               (const T*)x, (const T*)add, (T*)y, B, H, W, C, scale);
+        else
+            hipLaunchKernelGGL((pool2x2_kernel<T, 1>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, as_stream(stream),
+                               (const T*)x, (const T*)add, (T*)y, B, H, W, C, scale);
+    });
+    VAMD_LAUNCH_OK("vamd_pool2x2");
+    return 0;
+}
+
+int vamd_unpool2x2(const void* x, const void* add, void* y, int B, int Hs, int Ws, int C, int H, int W, float scale, int dtype,
+                   void* stream) {
+    VAMD_REQUIRE(x && y && B > 0 && Hs > 0 && Ws > 0 && C > 0, "vamd_unpool2x2: bad argument");
+    VAMD_REQUIRE(H / 2 == Hs && W / 2 == Ws, "vamd_unpool2x2: output %d x %d is not twice %d x %d (plus at most one)", H, W, Hs, Ws);
+    const int64_t total = (int64_t)B * H * W * C;
+    VAMD_DISPATCH(dtype, "vamd_unpool2x2", {
+        constexpr int V = Vec16<T>::N;
+        const bool vec = C % V == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)add % 16 == 0;
+        if (vec)
+            hipLaunchKernelGGL((unpool2x2_kernel<T, V>), dim3(grid_for(total / V, 256, 65536)), dim3(256), 0, as_stream(stream),
+                               (const T*)x, (const T*)add, (T*)y, B, Hs, Ws, C, H, W, scale);
+        else
+            hipLaunchKernelGGL((unpool2x2_kernel<T, 1>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, as_stream(stream),
+                               (const T*)x, (const T*)add, (T*)y, B, Hs, Ws, C, H, W, scale);
+    });
+    VAMD_LAUNCH_OK("vamd_unpool2x2");
     return 0;
 }
 

@@ -451,28 +451,54 @@ class _AttnBlock:
 
 
 class _Resample:
-    """DownBlock (conv 3x3 stride 2) / UpBlock (nearest 2x upsample fused into a conv 3x3);
+    """DownBlock (conv 3x3 stride 2, or AvgPool2d((2, 2)) when the model is built with with_conv false) /
+    UpBlock (nearest 2x upsample, fused into the conv 3x3 that follows it when there is one);
     reference models/ddpm.py:14-41."""
 
     def __init__(self, eng, spec: LayerSpec):
         p = spec.prefix
         self.eng, self.spec = eng, spec
-        if spec.kind == "down":
+        self.down = spec.kind == "down"
+        if not eng.plan.with_conv:
+            self.conv = None
+        elif self.down:
             self.conv = _Conv(eng, p + ".layers.0", spec.cin, spec.cout, 3, stride=2)
         else:
             self.conv = _Conv(eng, p + ".layers.1", spec.cin, spec.cout, 3, up=True)
-        self.convs = [self.conv]
+        self.convs = [self.conv] if self.conv is not None else []
+
+    def _pool(self, x, add, scale):
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+        call("vamd_pool2x2", _ptr(x), _ptr(add), _ptr(y), B, H, W, Cc, scale, self.eng.dt, _stream())
+        return y
+
+    def _unpool(self, x, add, scale, H, W):
+        B, Hs, Ws, Cc = x.shape
+        y = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
+        call("vamd_unpool2x2", _ptr(x), _ptr(add), _ptr(y), B, Hs, Ws, Cc, H, W, scale, self.eng.dt, _stream())
+        return y
 
     def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
-        y = self.conv.fwd(x, res2=res2, want_stats=want_stats)
+        if self.conv is not None:
+            y = self.conv.fwd(x, res2=res2, want_stats=want_stats)
+        elif self.down:
+            y = self._pool(x, res2, 0.25)
+        else:
+            y = self._unpool(x, res2, 1.0, 2 * x.shape[1], 2 * x.shape[2])
         if tape is not None:
-            tape.append((self, (x,)))
+            tape.append((self, (x,) if self.conv is not None else (x.shape,)))
         return y
 
     def bwd(self, saved, dy, extra, dtemb, need_dx=True):
-        (x,) = saved
-        self.conv.wgrad(dy, x)
-        return self.conv.dgrad(dy, x.shape, add=extra)
+        if self.conv is not None:
+            (x,) = saved
+            self.conv.wgrad(dy, x)
+            return self.conv.dgrad(dy, x.shape, add=extra)
+        (shape,) = saved
+        if self.down:
+            return self._unpool(dy, extra, 0.25, shape[1], shape[2])
+        return self._pool(dy, extra, 1.0)
 
 
 class Engine:
@@ -480,8 +506,6 @@ class Engine:
         params = list(module.named_parameters())
         if not params or params[0][1].device.type != "cuda":
             raise RuntimeError("vision_amd needs its parameters on a HIP device (cuda:N); there is no CPU path")
-        if not plan.with_conv:
-            raise NotImplementedError("with_conv=False (AvgPool2d / bare Upsample resampling) has no HIP kernels yet")
         self.device = params[0][1].device
         self.plan, self.dtype, self.algo = plan, dtype, algo
         self.stats_for: Dict[int, tuple] = {}      # output data_ptr -> (partial sums, parts) left by a conv epilogue
@@ -581,7 +605,8 @@ class Engine:
         return sorted(first.values())
 
     def _layer_low(self, prefix):
-        return min(off for name, (off, n) in self.param_slices.items() if name.startswith(prefix + "."))
+        """Lowest arena offset of the layer's parameters; None for a layer without any (pooling / bare upsampling)."""
+        return min((off for name, (off, n) in self.param_slices.items() if name.startswith(prefix + ".")), default=None)
 
     # ---- parameter access for the layer objects
     def param(self, name):
@@ -736,7 +761,7 @@ class Engine:
                 # for up modules i-1 >= nd, hence extra is None and g_in is exactly that gradient.
                 dskip[nd - 1 - j] = g_in
             g = g_in
-            if red is not None:
+            if red is not None and self._lows[layer.spec.prefix] is not None:
                 red.layer_done(self._lows[layer.spec.prefix])
         tag, (emb, t1, temb) = tape.pop()
         assert tag == "temb"

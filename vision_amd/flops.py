@@ -26,11 +26,11 @@ def forward_flops_per_image(config):
             s = res * res
             total += 4 * conv_flops(spec.cout, spec.cout, 1, res, res) + 2 * (2.0 * s * s * spec.cout)
         elif spec.kind == "down":
-            res = (res - 1) // 2 + 1
-            total += conv_flops(spec.cin, spec.cout, 3, res, res)
+            res = (res - 1) // 2 + 1 if plan.with_conv else res // 2
+            total += conv_flops(spec.cin, spec.cout, 3, res, res) if plan.with_conv else 0.0   # AvgPool2d otherwise
         else:
             res = res * 2
-            total += conv_flops(spec.cin, spec.cout, 3, res, res)
+            total += conv_flops(spec.cin, spec.cout, 3, res, res) if plan.with_conv else 0.0   # bare Upsample otherwise
     total += conv_flops(plan.end_channels, plan.end_channels, 1, res, res)
     return total, skip
 

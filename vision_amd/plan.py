@@ -64,7 +64,8 @@ def make_plan(config) -> UNetPlan:
             layers.append(LayerSpec("Downsampling", pos, "attn", width, width, int(res), int(res)))
             pos += 1
         if down_flags[lvl + 1] == 1:
-            half = (int(res) - 1) // 2 + 1                   # conv 3x3 stride 2 pad 1 (== res/2 for even res)
+            # conv 3x3 stride 2 pad 1 (== res/2 for even res); AvgPool2d((2, 2)) floors
+            half = (int(res) - 1) // 2 + 1 if bool(config["with_conv"]) else int(res) // 2
             layers.append(LayerSpec("Downsampling", pos, "down", width, width, int(res), half))
             pos += 1
             res = res / 2
