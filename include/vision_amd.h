@@ -372,6 +372,22 @@ int vamd_vq_backward(const float* z, const float* codebook, const int64_t* indic
                      const float* g_loss, int64_t M, int D, int K, int HW, int nchw, float beta, float* dz,
                      float* dcodebook, void* stream);
 
+/* ---- input pipeline: Resize((p, p)) + ToTensor of the data module on the GPU --------------------------- */
+/* Replaces the per-sample transform of ImageFolderDataModule (reference dataloader.py:32-36): torchvision's
+ * Resize on a PIL image (Pillow's two-pass antialiased bilinear resampler on 8-bit data, Pillow 12.2
+ * src/libImaging/Resample.c) followed by ToTensor (uint8 HWC -> fp32 CHW / 255).  Bit-identical to that path.
+ * vamd_resize_ksize / vamd_resize_coeffs (host only, no GPU): the window [bounds[2i], bounds[2i] + bounds[2i+1]) and
+ * the ksize 22-bit fixed-point weights of output coordinate i for an axis resized from in_size to out_size.
+ * vamd_image_resize_u8: src [H][W][pixel_bytes] uint8 in device memory (pixel_bytes 3: packed RGB; 4: RGB + one pad
+ * byte, Pillow's own storage of an RGB image) -> dst_chw [3][Ho][Wo] fp32 in [0, 1] and / or
+ * dst_u8 [Ho][Wo][3]; the tables of an axis are passed (device memory) exactly when its size changes; tmp
+ * [H][Wo][3] uint8 holds the horizontal pass (needed when W != Wo). */
+int vamd_resize_ksize(int in_size, int out_size);
+int vamd_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coef, int ksize);
+int vamd_image_resize_u8(const uint8_t* src, int H, int W, int pixel_bytes, const int32_t* hbounds, const int32_t* hcoef, int hk,
+                         const int32_t* vbounds, const int32_t* vcoef, int vk, uint8_t* tmp, int Ho, int Wo,
+                         float* dst_chw, uint8_t* dst_u8, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

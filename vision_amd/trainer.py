@@ -88,9 +88,15 @@ class ImageFolderDataModule:
     EXT = (".jpg", ".jpeg", ".png", ".bmp", ".webp")
 
     def __init__(self, data_dir, json_dir=None, patch_size=224, batch_size=32, num_workers=4, val_split=0.1,
-                 test_split=0.1, use_manual_split=False, device="cpu", **_):
+                 test_split=0.1, use_manual_split=False, device="cpu", gpu_transform=None, **_):
+        """gpu_transform (default: on when `device` is a HIP device): images are decoded by `num_workers` host
+        threads and resized / converted on the GPU, bit-identical to the PIL path (vision_amd.input_pipeline);
+        off: every sample is resized and converted on the host, as the reference's DataLoader workers do."""
         self.data_dir, self.patch_size, self.batch_size = data_dir, patch_size, batch_size
         self.val_split, self.test_split, self.use_manual_split, self.device = val_split, test_split, use_manual_split, device
+        self.num_workers = num_workers
+        self.gpu_transform = gpu_transform            # None: decided by the device the loaders run for
+        self._pipeline = None
         self._epoch_seed = 0
 
     def _scan(self, root):
@@ -145,8 +151,19 @@ class ImageFolderDataModule:
         else:
             order = list(range(len(items)))
         order = self.shard(order, rank, world)
-        for i in range(0, len(order), self.batch_size):
-            chunk = [items[j] for j in order[i:i + self.batch_size]]
+        chunks = [[items[j] for j in order[i:i + self.batch_size]] for i in range(0, len(order), self.batch_size)]
+        on_gpu = torch.device(self.device).type == "cuda"
+        if self.gpu_transform and not on_gpu:
+            raise ValueError("gpu_transform needs the data module's device to be a HIP device (cuda:N)")
+        if on_gpu if self.gpu_transform is None else self.gpu_transform:
+            if self._pipeline is None or self._pipeline.device != torch.device(self.device):
+                from .input_pipeline import GpuImagePipeline
+                self._pipeline = GpuImagePipeline(self.patch_size, self.device, workers=max(1, int(self.num_workers)))
+            xs = self._pipeline.batches([[p for p, _ in chunk] for chunk in chunks])
+            for chunk, x in zip(chunks, xs):
+                yield x, torch.tensor([c for _, c in chunk], dtype=torch.int64).to(self.device, non_blocking=True)
+            return
+        for chunk in chunks:
             x = torch.stack([self._load(p) for p, _ in chunk])
             y = torch.tensor([c for _, c in chunk], dtype=torch.int64)
             yield x.to(self.device), y.to(self.device)
