@@ -255,29 +255,48 @@ __global__ void bn_bwd_finalize_img_kernel(const float* __restrict__ partial, in
                                            float* __restrict__ dsum, float* __restrict__ dsum_total,
                                            int fixed_stats) {
     const int c = blockIdx.x, lane = threadIdx.x;
+    // totals over every (image, chunk) pair, pairs dealt to the lanes
     double t1 = 0.0, t2 = 0.0;
-    for (int b = lane; b < B; b += 64) {
-        for (int k = 0; k < nchunk; ++k) {
-            const float* q = partial + (((int64_t)b * nchunk + k) * C + c) * 3;
-            t1 += (double)q[0];
-            t2 += (double)q[1];
-        }
+    const int pairs = B * nchunk;
+    for (int i = lane; i < pairs; i += 64) {
+        const float* q = partial + ((int64_t)i * C + c) * 3;
+        t1 += (double)q[0];
+        t2 += (double)q[1];
     }
     const double s1 = wave_sum_d(t1), s2 = wave_sum_d(t2);
     const double count = hw * B;
     const double sc = (double)scale[c];
     const double a = sc, bq = fixed_stats ? 0.0 : -sc * s1 / count, cq = fixed_stats ? 0.0 : -sc * s2 / count;
     double tot = 0.0;
-    for (int b = lane; b < B; b += 64) {
-        double g1 = 0.0, g3 = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
-            const float* q = partial + (((int64_t)b * nchunk + k) * C + c) * 3;
-            g1 += (double)q[0];
-            g3 += (double)q[2];
+    if (nchunk >= 16) {
+        // few images with many chunks each (large feature maps): the lanes share one image's chunks
+        for (int b = 0; b < B; ++b) {
+            double g1 = 0.0, g3 = 0.0;
+            for (int k = lane; k < nchunk; k += 64) {
+                const float* q = partial + (((int64_t)b * nchunk + k) * C + c) * 3;
+                g1 += (double)q[0];
+                g3 += (double)q[2];
+            }
+            g1 = wave_sum_d(g1);
+            g3 = wave_sum_d(g3);
+            const double d = a * g1 + cq * g3 + hw * bq;
+            if (lane == 0) {
+                dsum[(int64_t)b * C + c] = (float)d;
+                tot += d;
+            }
         }
-        const double d = a * g1 + cq * g3 + hw * bq;
-        dsum[(int64_t)b * C + c] = (float)d;
-        tot += d;
+    } else {
+        for (int b = lane; b < B; b += 64) {
+            double g1 = 0.0, g3 = 0.0;
+            for (int k = 0; k < nchunk; ++k) {
+                const float* q = partial + (((int64_t)b * nchunk + k) * C + c) * 3;
+                g1 += (double)q[0];
+                g3 += (double)q[2];
+            }
+            const double d = a * g1 + cq * g3 + hw * bq;
+            dsum[(int64_t)b * C + c] = (float)d;
+            tot += d;
+        }
     }
     tot = wave_sum_d(tot);
     if (lane != 0) return;
