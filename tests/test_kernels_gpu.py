@@ -188,6 +188,14 @@ def test_conv_wide_tiles(case):
             call("vamd_conv2d_dgrad", C.byref(d), P(dyn), P(wd), P(addn), P(dx), P(ws), nb, S())
         assert relerr(dx.permute(0, 3, 1, 2), gx + add64) < TOL_OUT["bf16"], name
         outs[name] = (y, dx)
+        # bias-only forward and a plain (not accumulating) input gradient: the form the ping-pong kernel takes by default
+        y0 = torch.full((B, Ho, Wo, Cout), 7.0, dtype=tdt, device=DEV)
+        call("vamd_conv2d_fwd", C.byref(d), P(xn), P(wf), P(bias.to(DEV)), None, None, None, P(y0), S())
+        assert relerr(y0.permute(0, 3, 1, 2), y64.detach() + bias.double()[None, :, None, None]) < TOL_OUT["bf16"], name
+        if not up:
+            dx0 = torch.full((B, H, W, Cin), 7.0, dtype=tdt, device=DEV)
+            call("vamd_conv2d_dgrad", C.byref(d), P(dyn), P(wd), None, P(dx0), P(ws), nb, S())
+            assert relerr(dx0.permute(0, 3, 1, 2), gx) < TOL_OUT["bf16"], name
     if not split:
         return
     # same inputs, same split: bit-reproducible; against whole tiles: rounding of a different summation order

@@ -1952,7 +1952,9 @@ int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype) {
     }
     if (dtype == VAMD_BF16) {                             // as run_nt picks the ping-pong kernel
         const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
-        const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
+        // the question is asked for a launch that does sum statistics: any non-null pointer stands for its buffer
+        static float stats_wanted;
+        const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, &stats_wanted, (unsigned char*)g.scratch, g.scratch_bytes};
         if (nt8_applicable(gp, g.Cout, gp.Ktot, g.Cout, ep, 1)) return nt8_stats_parts(gp, g.Cout, ep);
     }
     if (dtype == VAMD_BF16 && nt_wide256(g.Cout, g.M, 1, 2, g.k * g.k * g.Cin, g.up != 0)) return ntp_row_groups((int)((g.M + 255) / 256), g.Cout / 256, 1);
