@@ -157,7 +157,10 @@ def test_backward_exact_inputs(golden, mode):
     e_all = rel(_cat(grads, keys), _cat(g64, keys))
     # a float32 forward may round a few pred - eps differences to the other side of zero than the
     # exact one does (the reference's own fp32 run does): allow what the reference itself shows
-    assert e_all < (max(1e-5, 4 * e32_all) if dtype == torch.float32 else max(8e-2, 2 * ebf_all)), e_all
+    # bf16: measured 0.030-0.058 over the four configurations against 0.027-0.064 for the reference's own bf16
+    # autocast on the same inputs (tests/diag_bf16_bounds_gpu.py): the bound is 1.5 x the reference's error, which is
+    # 1.1-1.7 x what the engine shows; per tensor the engine reaches at most 2.3 x the reference's error (bound: 3 x)
+    assert e_all < (max(1e-5, 4 * e32_all) if dtype == torch.float32 else 1.5 * ebf_all), e_all
 
 
 def test_loss_grads_bnstats(golden, mode):

@@ -487,9 +487,10 @@ bool nt8_applicable(const Gather& gp, int N, int ldw, int ldc, const Epilogue& e
     // Measured on MI355X against the 4-wave kernel (64 images): +4..7 % with 128-channel column tiles, +2 % on
     // 128 -> 256 channels at 56 x 56, -2..-5 % on 256- and 512-channel 3 x 3 layers (deeper reductions, fewer
     // tiles per CU), so the 256-wide tile serves short reductions only.
-    // With epilogue terms the 4-wave kernels win (measured, 128 -> 128 channels at 112 x 112 x 64 images: residual
-    // 401 vs 368 us, residual + skip 485 vs 389 us, accumulating input gradient 389 vs 361 us): their two workgroups
-    // per CU overlap one's epilogue loads with the other's MFMAs, the single 8-wave workgroup here cannot.
+    // With epilogue terms the older kernels win (measured, 128 -> 128 channels at 112 x 112 x 64 images: residual
+    // 401 vs 368 us, residual + skip 485 vs 389 us, accumulating input gradient 389 vs 361 us): all eight waves
+    // here reach the epilogue of their 128 x 64 wave tiles together and wait for the terms' loads with no MFMA
+    // work left to cover them.
     static const int with_terms = nt8_env("VAMD_NT8_TERMS", 0);
     if (!with_terms && (ep.temb || ep.res || ep.res2 || ep.stats)) return false;
     static const int wide_k = nt8_env("VAMD_NT8_WIDE_K", 1152);
