@@ -145,6 +145,13 @@ int vamd_conv2d_wgrad_oihw(const vamd_conv_desc* d, const void* dy, const void* 
                            void* workspace, size_t workspace_bytes, void* stream);
 size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d);
 
+/* Tuning control, process-wide: with a scratch buffer in the descriptor, 3x3 / 4x4 layers that have fewer tiles than the
+ * chip has CUs and a reduction of at least 8 K-steps per filter row run one workgroup set per filter row and add the
+ * fp32 partial products in a second, small kernel (same epilogue terms, one rounding; results differ from the unsplit
+ * launch by fp32 summation order only).  mode 1 (default): as described; 0: never split; other values: query only.
+ * Returns the previous mode.  Whether a layer splits depends on its batch size, so callers that compare batch sizes bit
+ * for bit switch it off. */
+int vamd_conv_splitk(int mode);
 /* 1 if the MFMA implicit-GEMM kernels serve this descriptor for pass 0 (forward), 1 (input
  * gradient) or 2 (weight gradient), 0 if the direct kernels do. */
 int vamd_conv2d_uses_mfma(const vamd_conv_desc* d, int pass);

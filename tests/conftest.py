@@ -60,3 +60,13 @@ def _conv_scratch_for_every_descriptor():
     _lib.set_default_scratch(buf)
     yield
     _lib.set_default_scratch(None)
+
+
+@pytest.fixture
+def no_splitk():
+    """Whole-tile convolution launches only: whether a layer's reduction is split depends on its batch size, and tests
+    that compare batch sizes bit for bit need one summation order."""
+    from vision_amd._lib import lib
+    old = lib.vamd_conv_splitk(0)
+    yield
+    lib.vamd_conv_splitk(old)

@@ -58,7 +58,7 @@ FFHQ_CASES = [
 
 
 @pytest.mark.parametrize("case", FFHQ_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_ffhq_conv_layers(case):
+def test_ffhq_conv_layers(case, no_splitk):
     B, H, W, Cin, Cout, k, stride, up = case
     gen = torch.Generator().manual_seed(13)
     pad = 1 if k == 3 else 0
@@ -195,7 +195,7 @@ def test_ffhq_wiring_against_oracle(mode):
     assert relerr(got_img, want_img) < (1e-4 if mode == "fp32" else 3e-2)
 
 
-def test_ffhq_full_size_batch_independence_and_reproducible_step():
+def test_ffhq_full_size_batch_independence_and_reproducible_step(no_splitk):
     cfg = dict(get_preset("ffhq")["model_config"], dropout=0.0)
     torch.manual_seed(cfg["manual_seed"])
     model = vision_amd.get_model("ddpm", cfg, compute_dtype="bf16").to(DEV)

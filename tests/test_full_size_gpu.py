@@ -94,7 +94,7 @@ def _run(case, B, x, wf, wd, dy, bias, with_dbias=True):
 
 
 @pytest.mark.parametrize("case", FULL_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_full_size_conv_layers(case):
+def test_full_size_conv_layers(case, no_splitk):
     B, H, W, Cin, Cout, k, stride, up = case
     gen = torch.Generator().manual_seed(11)
     pad = 1 if k == 3 else 0
@@ -188,7 +188,7 @@ def test_full_resolution_model_against_oracle(mode, fuse_shortcut, monkeypatch):
     assert err < (2e-3 if mode == "fp32" else 5e-2), err
 
 
-def test_full_batch_forward_is_batch_independent_and_step_is_reproducible():
+def test_full_batch_forward_is_batch_independent_and_step_is_reproducible(no_splitk):
     model, cfg, _, _ = _butterfly_model("bf16")
     P_, B = cfg["patch_size"], 64
     gen = torch.Generator(device=DEV).manual_seed(5)

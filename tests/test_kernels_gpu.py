@@ -795,3 +795,72 @@ def test_pool_and_unpool_2x2(shape, dts):
     ds = torch.full((B, Ho, Wo, Cc), 7.0, dtype=tdt, device=DEV)
     call("vamd_pool2x2", P(nhwc(du)), P(addn), P(ds), B, 2 * Ho, 2 * Wo, Cc, 1.0, dt, S())
     assert relerr(ds.permute(0, 3, 1, 2), gs + add64) < tol
+
+
+# Layers with fewer tiles than CUs and long reductions: with a scratch buffer in the descriptor the filter rows are
+# computed by separate workgroup sets and added by a second kernel.  B, H, W, Cin, Cout, k, stride, up
+SPLITK_CASES = [
+    (16, 14, 14, 512, 512, 3, 1, 0),      # the flowers / sampler-batch shape: 100 tiles, 72 K-steps
+    (2, 14, 14, 512, 512, 3, 1, 0),
+    (4, 32, 32, 256, 256, 3, 1, 0),       # ffhq at 4 images
+    (3, 9, 11, 256, 384, 3, 1, 0),        # 48 column threads in the adding kernel: 5 row lanes, 16 threads idle
+    (1, 20, 26, 256, 64, 3, 1, 0),        # 64-channel column tile
+    (5, 7, 7, 512, 256, 3, 1, 0),         # ragged last block of rows
+]
+
+
+@pytest.mark.parametrize("dts", ["bf16", "f32"])
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_split_reduction(case, dts):
+    """Forward (bias, time embedding, residual, skip, fused BatchNorm statistics) and accumulating input gradient with
+    the reduction split by filter rows, against fp64 and against the unsplit launch (fp32 summation order differs)."""
+    B, H, W, Cin, Cout, k, stride, up = case
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(sum(case) + 1)
+    x, x64 = rnd((B, Cin, H, W), tdt, gen)
+    _, w64 = rnd((Cout, Cin, k, k), tdt, gen, 1.0 / math.sqrt(Cin * k * k))
+    wf, wd = pack_weights(w64, tdt, dt)
+    bias, temb = torch.randn(Cout, generator=gen), torch.randn(B, Cout, generator=gen)
+    x64 = x64.requires_grad_(True)
+    y64 = conv_ref(x64, w64, stride, up, k)
+    res, res64 = rnd(tuple(y64.shape), tdt, gen)
+    res2, res264 = rnd(tuple(y64.shape), tdt, gen)
+    dy, dy64 = rnd(tuple(y64.shape), tdt, gen)
+    add, add64 = rnd((B, Cin, H, W), tdt, gen)
+    want = y64.detach() + bias.double()[None, :, None, None] + temb.double()[:, :, None, None] + res64 + res264
+    (gx,) = torch.autograd.grad(y64, [x64], dy64)
+    xn, dyn, resn, res2n, addn = nhwc(x), nhwc(dy), nhwc(res), nhwc(res2), nhwc(add)
+    scratch = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=DEV)
+    tol = TOL_OUT[dts]
+    outs, parts = {}, {}
+    old = lib.vamd_conv_splitk(-1)
+    try:
+        for mode in (1, 0):
+            lib.vamd_conv_splitk(mode)
+            d = ConvDesc(B, H, W, Cin, Cout, k, stride, 1, up, dt, _lib.ALGO_MFMA)
+            d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
+            nparts = lib.vamd_conv2d_stats_parts(C.byref(d))
+            assert nparts > 0
+            parts[mode] = nparts
+            y = torch.full((B, H, W, Cout), 7.0, dtype=tdt, device=DEV)
+            part = torch.full((nparts, Cout, 2), 7.0, dtype=torch.float32, device=DEV)
+            call("vamd_conv2d_fwd_stats", C.byref(d), P(xn), P(wf), P(bias.to(DEV)), P(temb.to(DEV)), P(resn), P(res2n), P(y),
+                 P(part), S())
+            yd = y.double().cpu().reshape(-1, Cout)
+            assert relerr(part.sum(0), torch.stack([yd.sum(0), (yd * yd).sum(0)], 1)) < 1e-5, mode
+            assert relerr(y.permute(0, 3, 1, 2), want) < tol, mode
+            y0 = torch.full((B, H, W, Cout), 7.0, dtype=tdt, device=DEV)
+            call("vamd_conv2d_fwd", C.byref(d), P(xn), P(wf), None, None, None, None, P(y0), S())
+            assert relerr(y0.permute(0, 3, 1, 2), y64.detach()) < tol, mode
+            dx = torch.full((B, H, W, Cin), 7.0, dtype=tdt, device=DEV)
+            nb = lib.vamd_conv2d_dgrad_workspace(C.byref(d))
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+            call("vamd_conv2d_dgrad", C.byref(d), P(dyn), P(wd), P(addn), P(dx), P(ws), nb, S())
+            assert relerr(dx.permute(0, 3, 1, 2), gx + add64) < tol, mode
+            outs[mode] = (y, dx)
+    finally:
+        lib.vamd_conv_splitk(old)
+    rows = 16
+    assert parts[1] == (B * H * W + rows - 1) // rows and parts[1] != parts[0], parts      # the split form did run
+    assert relerr(outs[1][0], outs[0][0].double()) < (2e-3 if dts == "bf16" else 1e-6)
+    assert relerr(outs[1][1], outs[0][1].double()) < (2e-3 if dts == "bf16" else 1e-6)

@@ -139,6 +139,8 @@ int vamd_conv2d_stats_parts(const vamd_conv_desc* d) {
     return a == kMfma ? conv_fwd_mfma_stats_parts(g, d->dtype) : 0;
 }
 
+int vamd_conv_splitk(int mode) { return conv_splitk_mode(mode); }
+
 int vamd_conv2d_uses_mfma(const vamd_conv_desc* d, int pass) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_uses_mfma")) return 0;

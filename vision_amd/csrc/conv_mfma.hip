@@ -14,6 +14,7 @@
 //
 // Element types: bf16 (v_mfma_f32_16x16x32_bf16) and fp32 (v_mfma_f32_16x16x4_f32, exact fp32).
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 #include "conv_shapes.h"
@@ -333,6 +334,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     const int wm = wave >> 1, wn = wave & 1;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     int blk = blockIdx.x, nblk = gridDim.x;
+    int64_t yoff = 0;
     if (cs.ncls > 1) {                                     // this workgroup's class (uniform)
         const int c = (blk >= cs.first_block[1]) + (blk >= cs.first_block[2]) + (blk >= cs.first_block[3]);
         gp = cs.g[c];
@@ -340,6 +342,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         row_tiles = m_tiles;
         w += cs.w_off[c];
         if (ep.stats) ep.stats += cs.stats_off[c];
+        yoff = cs.y_off[c];
         nblk = cs.first_block[c + 1] - cs.first_block[c];
         blk -= cs.first_block[c];
     }
@@ -538,7 +541,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     };
     auto write_tile = [&](int row_tile) {
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
-        epilogue_rows<T, NT, STATS>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC,
+        epilogue_rows<T, NT, STATS>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC + yoff,
                                     (uint32_t)(mt * kBM + wm * 64 + frow), nb);
     };
 
@@ -644,6 +647,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     const int wm = wave >> 1, wn = wave & 1;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     int blk = blockIdx.x, nblk = gridDim.x;
+    int64_t yoff = 0;
     if (cs.ncls > 1) {                                     // this workgroup's class (uniform)
         const int c = (blk >= cs.first_block[1]) + (blk >= cs.first_block[2]) + (blk >= cs.first_block[3]);
         gp = cs.g[c];
@@ -651,6 +655,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         row_tiles = m_tiles;
         w += cs.w_off[c];
         if (ep.stats) ep.stats += cs.stats_off[c];
+        yoff = cs.y_off[c];
         nblk = cs.first_block[c + 1] - cs.first_block[c];
         blk -= cs.first_block[c];
     }
@@ -844,7 +849,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     };
     auto write_tile = [&](int row_tile) {
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
-        epilogue_rows<T, NT, STATS_REG>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC,
+        epilogue_rows<T, NT, STATS_REG>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC + yoff,
                                         (uint32_t)(mt * BM + wm * 64 + frow), nb);
     };
 
@@ -857,7 +862,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
 #pragma unroll
         for (int e = 0; e < 16; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
         epilogue_rows<T, NT, STATS_LDS, (NT == 8 ? 16 * H : 0), (NT == 8 ? 16 : 4 * NT)>(
-            acc, t1, t2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC,
+            acc, t1, t2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC + yoff,
             (uint32_t)(mt * BM + wm * 64 + frow), nb);
         if constexpr (STATS_LDS) {
 #pragma unroll
@@ -1680,6 +1685,8 @@ static bool nt_classic() {
 // switches it off (side-by-side measurements).
 static bool nt_wide(int BN, int64_t M, int batch, int n_tiles) {
     static const int force = [] { const char* e = getenv("VAMD_NT_WIDE"); return e ? atoi(e) : -1; }();
+    // 128-row tiles for layers with few 256-row tiles win in isolation (4 x 64 x 64 x 256 channels: 37.9 -> 29.8 us) but
+    // lose inside the training step and the sampler (flowers 8.04 -> 8.14 / 8.18 ms with thresholds of 60 / 110 tiles)
     static const int min_tiles = [] { const char* e = getenv("VAMD_NT_WIDE_MIN"); return e ? atoi(e) : 1; }();
     if (BN != 128 || nt_classic() || force == 0) return false;
     return ((M + 255) / 256) * batch * n_tiles >= min_tiles;
@@ -1893,10 +1900,159 @@ static int launch_c64_halo(const HaloArgs& ha, const bf16_t* x, const bf16_t* w,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Split reduction for layers with fewer tiles than CUs and a long reduction (512 channels at 14 x 14 with 16 images:
+// 100 tiles of 72 K-steps each, one per workgroup, each step a full load-to-MFMA latency).  The filter rows become
+// up to four "classes" of one launch (ClassSet: same output rows, a one-row sub-filter view each), every class
+// stores its fp32 partial product into the caller's scratch buffer, and splitk_reduce_kernel adds the partials in
+// class order, applies the epilogue terms in the kernels' order (bias, time embedding, residual, skip), rounds
+// once and sums the following BatchNorm's statistics per block of rows.
+static std::atomic<int> g_splitk_mode{1};
+
+static int nt_split_rows(const Gather& gp, int N, int ldc, const Epilogue& ep, int batch, size_t elem) {
+    // tiles of the kernel that would run unsplit.  Measured: 16 x 14 x 14 x 512 channels (52 tiles of 72 K-steps)
+    // 69.9 -> 43.7 us, 4 x 16 x 16 x 256 (8 tiles of 36 K-steps) 28.6 -> 19.3 us; from 128 tiles on the split loses
+    // (4 x 64 x 64, 128 -> 256 channels: 29.0 -> 34.9 us).  In the step: flowers 8.22 -> 8.03 ms, its 16-image sampler
+    // 7630 -> 8000 image-steps/s, ffhq 16.49 -> 16.28 ms; thresholds of 104 / 136 / 200 tiles measure alike.
+    static const int max_tiles = [] { const char* e = getenv("VAMD_SPLITK_MAX_TILES"); return e ? atoi(e) : 104; }();
+    if (!g_splitk_mode.load() || nt_classic() || batch != 1 || gp.shift || gp.ostep || gp.stride != 1 || gp.Cin2 > 0) return 0;
+    if (ep.out_f32 || ep.alpha != 1.0f || ldc != N || !ep.scratch) return 0;
+    if (gp.kr != gp.k || gp.ks != gp.k || gp.k < 3 || gp.k > 4 || gp.wstep != 1) return 0;
+    const int piece = 16 / (int)elem;
+    if (N % piece != 0 || N / piece > 256 || gp.ldx != gp.Cin) return 0;
+    if ((int64_t)gp.ks * gp.Cin < 8 * (elem == 2 ? 64 : 32)) return 0;               // at least 8 K-steps per class
+    if (ep.scratch_bytes < 4096 + (size_t)gp.k * (size_t)gp.M * N * 4) return 0;
+    const int BN = N <= 64 ? 64 : 128, n_tiles = (N + BN - 1) / BN;
+    const int rows = nt_wide(BN, gp.M, 1, n_tiles) ? 256 : kBM;
+    const int64_t tiles = ((int64_t)gp.M + rows - 1) / rows * n_tiles;
+    return tiles <= max_tiles ? gp.k : 0;
+}
+
+static int splitk_rows_per_block(int64_t M) { return M <= 8192 ? 16 : (M <= 16384 ? 32 : 64); }
+static int splitk_stats_parts(int64_t M) { const int r = splitk_rows_per_block(M); return (int)((M + r - 1) / r); }
+
+template <typename T, bool STATS>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t MN, int M, int N, FastDiv div_howo, Epilogue ep,
+                     T* __restrict__ y, int rows_per_block) {
+    constexpr int PIECE = 16 / (int)sizeof(T);
+    __shared__ float red[256 * PIECE * 2];               // [row lane][N][2] (row lanes * N = 256 * PIECE at most)
+    const int tc = N / PIECE, tr = 256 / tc;
+    const int rl = threadIdx.x / tc, cl = threadIdx.x - rl * tc, n = cl * PIECE;
+    float s1[PIECE], s2[PIECE], bv[PIECE];
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) { s1[e] = 0.f; s2[e] = 0.f; bv[e] = 0.f; }
+    if (rl < tr) {
+        if (ep.bias) {
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) bv[e] = ep.bias[n + e];
+        }
+        const int r0 = blockIdx.x * rows_per_block;
+        const int r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+        const T* res = reinterpret_cast<const T*>(ep.res);
+        const T* res2 = reinterpret_cast<const T*>(ep.res2);
+        for (int row = r0 + rl; row < r1; row += tr) {
+            const int64_t off = (int64_t)row * N + n;
+            float v[PIECE];
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) v[e] = 0.f;
+            for (int s = 0; s < nsplit; ++s) {
+#pragma unroll
+                for (int e = 0; e < PIECE; e += 4) {
+                    const float4 p4 = *reinterpret_cast<const float4*>(part + (int64_t)s * MN + off + e);
+                    v[e] += p4.x; v[e + 1] += p4.y; v[e + 2] += p4.z; v[e + 3] += p4.w;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) v[e] += bv[e];
+            if (ep.temb) {
+                const float* tp = ep.temb + (int64_t)fdiv((uint32_t)row, div_howo) * N + n;
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[e] += tp[e];
+            }
+            if (res) {
+                const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res + off);
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[e] += to_f(rv.v[e]);
+            }
+            if (res2) {
+                const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res2 + off);
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) v[e] += to_f(rv.v[e]);
+            }
+            Vec16<T> ov;
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) ov.v[e] = from_f<T>(v[e]);
+            *reinterpret_cast<Vec16<T>*>(y + off) = ov;
+            if constexpr (STATS) {
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e) {
+                    const float q = to_f(ov.v[e]);
+                    s1[e] += q;
+                    s2[e] = fmaf(q, q, s2[e]);
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        if (rl < tr) {
+#pragma unroll
+            for (int e = 0; e < PIECE; ++e) {
+                red[(rl * N + n + e) * 2 + 0] = s1[e];
+                red[(rl * N + n + e) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < N * 2; idx += 256) {
+            float a = 0.f;
+            for (int r = 0; r < tr; ++r) a += red[r * N * 2 + idx];
+            ep.stats[(int64_t)blockIdx.x * N * 2 + idx] = a;
+        }
+    }
+}
+
+template <typename T>
+static int run_nt_split(const Gather& gp, const T* x, const T* w, int N, int ldw, const Epilogue& ep, void* y, int nsplit,
+                        hipStream_t st) {
+    ClassSet set;
+    set.ncls = 0;
+    const int64_t MN = (int64_t)gp.M * N;
+    for (int r = 0; r < nsplit; ++r) {
+        Gather g = gp;                                    // filter row r alone: taps (r, 0 .. ks-1)
+        g.kr = 1;
+        g.wr0 = gp.wr0 + r;
+        g.pad = gp.pad - r;                               // tap row 0 of the class reads input row ho + r - pad
+        g.Ktot = g.ks * g.Cin;
+        set.g[set.ncls] = g;
+        set.w_off[set.ncls] = 0;
+        set.stats_off[set.ncls] = 0;
+        set.y_off[set.ncls] = (int64_t)r * MN;
+        ++set.ncls;
+    }
+    float* part = reinterpret_cast<float*>(ep.scratch + 4096);
+    Epilogue pe{nullptr, nullptr, nullptr, nullptr, 1.0f, 1, nullptr, nullptr, 0};
+    int rc = N <= 64 ? launch_nt<T, 64, false>(set.g[0], x, w, N, ldw, N, pe, part, 1, 0, 0, 0, st, &set)
+                     : launch_nt<T, 128, false>(set.g[0], x, w, N, ldw, N, pe, part, 1, 0, 0, 0, st, &set);
+    if (rc) return rc;
+    const int rpb = splitk_rows_per_block(gp.M), blocks = splitk_stats_parts(gp.M);
+    if (ep.stats)
+        hipLaunchKernelGGL((splitk_reduce_kernel<T, true>), dim3(blocks), dim3(256), 0, st, part, nsplit, MN, gp.M, N,
+                           gp.div_howo, ep, (T*)y, rpb);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<T, false>), dim3(blocks), dim3(256), 0, st, part, nsplit, MN, gp.M, N,
+                           gp.div_howo, ep, (T*)y, rpb);
+    VAMD_LAUNCH_OK("splitk_reduce");
+    return 0;
+}
+
 template <typename T>
 static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep,
                   void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st,
                   const ClassSet* classes = nullptr) {
+    if (!classes) {
+        const int nsplit = nt_split_rows(gp, N, ldc, ep, batch, sizeof(T));
+        if (nsplit > 0) return run_nt_split<T>(gp, (const T*)x, (const T*)w, N, ldw, ep, y, nsplit, st);
+    }
     if constexpr (sizeof(T) == 2) {
         int pwl, tw, th, nt;
         if (!classes && c64_halo_gather(gp, N, ldw, ldc, ep, batch) && c64_halo_shape(gp.Hin, gp.Win, gp.M, &pwl, &tw, &th, &nt))
@@ -1946,6 +2102,11 @@ bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype) {
 int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype) {
     const int m_tiles = (int)((g.M + kBM - 1) / kBM);
     if (nt_classic()) return m_tiles;
+    {                                                     // as run_nt splits the reduction
+        const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
+        const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
+        if (nt_split_rows(gp, g.Cout, g.Cout, ep, 1, dtype == VAMD_BF16 ? 2 : 4) > 0) return splitk_stats_parts(g.M);
+    }
     if (dtype == VAMD_BF16 && g.Cin == 64 && (g.Cout == 64 || g.Cout == 128) && g.k == 3 && g.stride == 1 && g.pad == 1 && !g.up) {
         int pwl, tw, th, nt;                              // as run_nt picks the resident-filter kernel
         if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return c64_halo_blocks(nt, g.Cout / 64) / (g.Cout / 64);
@@ -1983,6 +2144,11 @@ bool conv_fwd_short_mfma_supported(const ConvGeom& g, int dtype, int Cin2) {
         int pwl, tw, th, nt;                              // the resident-filter kernel serves the plain conv: keep the two launches
         if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return false;
     }
+    {                                                     // likewise where the plain conv's reduction is split
+        const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
+        const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
+        if (nt_split_rows(gp, g.Cout, g.Cout, ep, 1, dtype == VAMD_BF16 ? 2 : 4) > 0) return false;
+    }
     if (dtype == VAMD_BF16) {                             // likewise where the ping-pong kernel serves the plain conv
         const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
         const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
@@ -2019,6 +2185,7 @@ static void fwd_up4_classes(const ConvGeom& g, ClassSet& set) {
             set.g[set.ncls] = gp;
             set.w_off[set.ncls] = (int64_t)set.ncls * g.Cout * 4 * g.Cin;
             set.stats_off[set.ncls] = 0;
+            set.y_off[set.ncls] = 0;
             ++set.ncls;
         }
 }
@@ -2151,6 +2318,7 @@ int conv_dgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* wt
                     set.g[set.ncls] = gp;
                     set.w_off[set.ncls] = 0;
                     set.stats_off[set.ncls] = 0;
+                    set.y_off[set.ncls] = 0;
                     ++set.ncls;
                     continue;
                 }
@@ -2526,4 +2694,12 @@ int bmm_tn_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N,
                             (int64_t)K * ldb, (int64_t)M * ldc, 1, C, alpha, nullptr, 0, st);
 }
 
+}  // namespace vamd
+
+namespace vamd {
+int conv_splitk_mode(int mode) {
+    const int old = g_splitk_mode.load();
+    if (mode == 0 || mode == 1) g_splitk_mode.store(mode);
+    return old;
+}
 }  // namespace vamd

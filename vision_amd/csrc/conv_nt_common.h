@@ -80,6 +80,7 @@ struct ClassSet {
     int m_tiles[4];
     int64_t w_off[4];          // elements added to the filter pointer
     int64_t stats_off[4];      // floats added to the statistics pointer
+    int64_t y_off[4];          // output elements added to every output offset (partial products of a split reduction)
     Gather g[4];
 };
 

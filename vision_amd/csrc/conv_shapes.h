@@ -17,6 +17,10 @@ struct ConvGeom {
 // Validates a vamd_conv_desc and fills `g`.  Returns 0 or a negative status (message set).
 int conv_geom(const vamd_conv_desc* d, ConvGeom* g, const char* who);
 
+// 1: layers with fewer tiles than CUs and a long reduction split it between workgroups (needs the descriptor's scratch
+// buffer); 0: never.  Returns the previous setting; any other value only queries.
+int conv_splitk_mode(int mode);
+
 // direct kernels (conv_direct.hip)
 int conv_fwd_direct(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
                     const float* temb, const void* res, const void* res2, void* y, hipStream_t st);

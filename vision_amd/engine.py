@@ -510,9 +510,8 @@ class Engine:
         self.plan, self.dtype, self.algo = plan, dtype, algo
         self.stats_for: Dict[int, tuple] = {}      # output data_ptr -> (partial sums, parts) left by a conv epilogue
         # zero-filled once, then owned by the kernels (flags and partial sums of tiles split between workgroups)
-        self.scratch = None
-        if dtype == torch.bfloat16 and os.environ.get("VAMD_NT8_STREAMK", "0") != "0":
-            self.scratch = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=self.device)
+        # (partial products of layers whose reduction is split between workgroups: the small, deep layers)
+        self.scratch = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=self.device)
         self.dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}[dtype]
 
         # one flat fp32 arena for parameters and one for gradients; every nn.Parameter becomes a view
