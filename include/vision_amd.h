@@ -76,6 +76,18 @@ int vamd_conv2d_fwd(const vamd_conv_desc* d, const void* x, const void* w, const
                     const float* temb, const void* residual, const void* residual2, void* y,
                     void* stream);
 
+/* Forward convolution with the CONSUMER's eval-mode BatchNorm + LeakyReLU folded into the epilogue: the sampler's
+ * `self.block2(...)` / next block's `self.block1(...)` prologue (reference models/ddpm.py:49-60 in eval mode, where the
+ * normalisation uses running statistics and is a per-channel affine map known before the producer runs).
+ *   q     = round_to_dtype(conv(x) + bias + temb + residual + residual2)        (what vamd_conv2d_fwd stores)
+ *   y     = round_to_dtype(leaky_relu(fma(q, scale[c], shift[c]), slope))       (what vamd_scale_shift_act makes of q)
+ *   y_raw = q, if y_raw != NULL (the pre-normalisation tensor, needed when it also feeds a shortcut or a skip)
+ * scale / shift: [Cout] fp32, 16-byte aligned.  Bit-identical to the two separate calls.  Kernels exist for the shapes
+ * for which vamd_conv2d_fwd_act_supported returns 1 (MFMA path, no upsampling gather). */
+int vamd_conv2d_fwd_act_supported(const vamd_conv_desc* d);
+int vamd_conv2d_fwd_act(const vamd_conv_desc* d, const void* x, const void* w, const float* bias, const float* temb,
+                        const void* residual, const void* residual2, const float* scale, const float* shift, float slope,
+                        void* y, void* y_raw, void* stream);
 /* vamd_conv2d_fwd that also emits what a BatchNorm2d over its output needs in training mode
  * (reference models/ddpm.py:52-53: block2 = BatchNorm2d(out) -> act -> Dropout -> Conv2d runs
  * on the output of block1's convolution; :47-48 the same for the next block's block1):

@@ -864,3 +864,68 @@ def test_conv_split_reduction(case, dts):
     assert parts[1] == (B * H * W + rows - 1) // rows and parts[1] != parts[0], parts      # the split form did run
     assert relerr(outs[1][0], outs[0][0].double()) < (2e-3 if dts == "bf16" else 1e-6)
     assert relerr(outs[1][1], outs[0][1].double()) < (2e-3 if dts == "bf16" else 1e-6)
+
+
+ACT_CASES = [
+    # B, H, W, Cin, Cout, k, stride   (which kernel serves the shape at bf16)
+    (2, 20, 24, 64, 64, 3, 1),          # resident-filter kernel
+    (2, 20, 24, 64, 128, 3, 1),         # ... two column tiles
+    (2, 16, 16, 128, 128, 3, 1),        # 256 x 128 tiles
+    (1, 24, 48, 128, 256, 3, 1),
+    (4, 64, 64, 256, 256, 3, 1),        # 256 x 256 tiles (>= 160 of them need a larger batch: falls to 256 x 128 here)
+    (2, 18, 18, 256, 512, 1, 1),        # 1 x 1
+    (1, 18, 22, 256, 256, 3, 2),        # stride 2 (DownBlock)
+    (2, 12, 12, 64, 64, 3, 2),
+    (3, 9, 7, 32, 64, 3, 1),            # 128 x 64 tiles
+    (16, 14, 14, 512, 512, 3, 1),       # split reduction (scratch buffer in the descriptor)
+    (2, 9, 9, 64, 96, 1, 1),            # ragged column tile
+]
+
+
+@pytest.mark.parametrize("dts", ["bf16", "f32"])
+@pytest.mark.parametrize("case", ACT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_forward_with_fused_eval_norm(case, dts):
+    """vamd_conv2d_fwd_act against vamd_conv2d_fwd followed by vamd_scale_shift_act: both outputs bit-identical, with
+    and without the raw output, with every epilogue term."""
+    B, H, W, Cin, Cout, k, stride = case
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(sum(case) + 3)
+    pad = 1 if k == 3 else 0
+    x, _ = rnd((B, Cin, H, W), tdt, gen)
+    _, w64 = rnd((Cout, Cin, k, k), tdt, gen, 1.0 / math.sqrt(Cin * k * k))
+    wf, _ = pack_weights(w64, tdt, dt)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    bias, temb = torch.randn(Cout, generator=gen).to(DEV), torch.randn(B, Cout, generator=gen).to(DEV)
+    res = torch.randn((B, Ho, Wo, Cout), generator=gen).to(DEV).to(tdt)
+    res2 = torch.randn((B, Ho, Wo, Cout), generator=gen).to(DEV).to(tdt)
+    scale = (torch.rand(Cout, generator=gen) + 0.5).to(DEV) * torch.where(torch.rand(Cout, generator=gen) < 0.2, -1.0, 1.0).to(DEV)
+    shift = torch.randn(Cout, generator=gen).to(DEV)
+    xn = nhwc(x)
+    scratch = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=DEV)
+    d = ConvDesc(B, H, W, Cin, Cout, k, stride, pad, 0, dt, _lib.ALGO_MFMA)
+    d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
+    assert lib.vamd_conv2d_fwd_act_supported(C.byref(d)) == 1
+    for terms in ((temb, res, res2), (None, None, None), (temb, None, None), (None, res, None)):
+        t_, r1, r2 = terms
+        q = torch.full((B, Ho, Wo, Cout), 7.0, dtype=tdt, device=DEV)
+        call("vamd_conv2d_fwd", C.byref(d), P(xn), P(wf), P(bias), P(t_), P(r1), P(r2), P(q), S())
+        want = torch.full_like(q, 7.0)
+        call("vamd_scale_shift_act", P(q), P(scale), P(shift), None, 0.01, 1.0, P(want), 1, B * Ho * Wo, Cout, dt, S())
+        for with_raw in (True, False):
+            y = torch.full_like(q, 5.0)
+            raw = torch.full_like(q, 5.0) if with_raw else None
+            call("vamd_conv2d_fwd_act", C.byref(d), P(xn), P(wf), P(bias), P(t_), P(r1), P(r2), P(scale), P(shift), 0.01, P(y),
+                 P(raw), S())
+            assert torch.equal(y, want), (terms[0] is not None, terms[1] is not None, with_raw)
+            if with_raw:
+                assert torch.equal(raw, q)
+
+
+def test_fused_eval_norm_refuses_what_it_cannot_do():
+    d = ConvDesc(2, 8, 8, 64, 64, 3, 1, 1, 1, _lib.BF16, _lib.ALGO_MFMA)       # upsampling gather
+    assert lib.vamd_conv2d_fwd_act_supported(C.byref(d)) == 0
+    d = ConvDesc(2, 8, 8, 3, 64, 3, 1, 1, 0, _lib.BF16, _lib.ALGO_AUTO)        # thin-channel kernel
+    assert lib.vamd_conv2d_fwd_act_supported(C.byref(d)) == 0
+    z = torch.zeros(64, device=DEV)
+    rc = lib.vamd_conv2d_fwd_act(C.byref(d), P(z), P(z), None, None, None, None, P(z), P(z), C.c_float(0.01), P(z), None, S())
+    assert rc != 0 and b"vamd_conv2d_fwd_act" in lib.vamd_last_error()

@@ -74,6 +74,8 @@ SIGNATURES = {
     "vamd_launch_timing_read": (C.c_long, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vamd_conv2d_fwd": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vamd_conv2d_fwd_stats": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "vamd_conv2d_fwd_act_supported": (_i, [_d]),
+    "vamd_conv2d_fwd_act": (_i, [_d, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p]),
     "vamd_conv2d_stats_parts": (_i, [_d]),
     "vamd_conv2d_fwd_short_supported": (_i, [_d, _i]),
     "vamd_conv2d_fwd_short": (_i, [_d, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),

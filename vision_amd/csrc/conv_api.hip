@@ -132,6 +132,30 @@ int vamd_conv2d_fwd_stats(const vamd_conv_desc* d, const void* x, const void* w,
     return conv2d_fwd_impl("vamd_conv2d_fwd_stats", d, x, w, bias, temb, residual, residual2, y, stats, stream);
 }
 
+int vamd_conv2d_fwd_act_supported(const vamd_conv_desc* d) {
+    ConvGeom g;
+    if (conv_geom(d, &g, "vamd_conv2d_fwd_act_supported")) return 0;
+    const int a = pick(d->algo, conv_thin_supported(g, d->dtype), conv_fwd_mfma_supported(g, d->dtype), "", g);
+    return a == kMfma && conv_fwd_act_mfma_supported(g, d->dtype) ? 1 : 0;
+}
+
+int vamd_conv2d_fwd_act(const vamd_conv_desc* d, const void* x, const void* w, const float* bias, const float* temb,
+                        const void* residual, const void* residual2, const float* scale, const float* shift, float slope,
+                        void* y, void* y_raw, void* stream) {
+    const char* who = "vamd_conv2d_fwd_act";
+    ConvGeom g;
+    int rc = conv_geom(d, &g, who);
+    if (rc) return rc;
+    VAMD_REQUIRE(x && w && y && scale && shift, "%s: null tensor", who);
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)y_raw % 16 == 0 &&
+                 (uintptr_t)scale % 16 == 0 && (uintptr_t)shift % 16 == 0, "%s: tensors must be 16-byte aligned", who);
+    if (!vamd_conv2d_fwd_act_supported(d))
+        return fail(VAMD_EUNSUPPORTED, "%s: no kernel with a fused normalise for Cin=%d Cout=%d k=%d upsample=%d (ask "
+                    "vamd_conv2d_fwd_act_supported first)", who, g.Cin, g.Cout, g.k, g.up);
+    return conv_fwd_act_mfma(g, d->dtype, x, w, bias, temb, residual, residual2, scale, shift, slope, y, y_raw,
+                             as_stream(stream));
+}
+
 int vamd_conv2d_stats_parts(const vamd_conv_desc* d) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_stats_parts")) return 0;

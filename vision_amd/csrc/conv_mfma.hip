@@ -313,7 +313,7 @@ conv_nt_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w,
 //     output channels, columns = pixels) and the filter rows are permuted inside the LDS tile, so
 //     every lane ends up with 4*NT consecutive channels of one pixel (no LDS pass, no barrier);
 //   * fused column statistics are kept in registers across the tiles and reduced once.
-template <typename T, int BN, int GM, bool STATS>            // GM: 0 plain gather, 1 upsampling gather, 2 second source
+template <typename T, int BN, int GM, int EPI>               // GM: 0 plain gather, 1 upsampling gather, 2 second source; EPI: 0 plain, 1 statistics, 2 fused normalise
 __global__ void __launch_bounds__(256, BN == 64 ? 3 : 2)
 conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
                      Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, int row_tiles,
@@ -324,6 +324,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     constexpr int A_BYTES = kBM * kRowBytes;
     constexpr int B_BYTES = BN * kRowBytes;
     constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr bool STATS = EPI == 1, ACT = EPI == 2;
     constexpr int NT = BN / 32;                           // 16-wide channel tiles per wave
     constexpr int CPL = 4 * NT;                           // consecutive output channels per lane
     using Frag = typename ElemTraits<T>::Frag;
@@ -541,8 +542,9 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     };
     auto write_tile = [&](int row_tile) {
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
-        epilogue_rows<T, NT, STATS>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC + yoff,
-                                    (uint32_t)(mt * kBM + wm * 64 + frow), nb);
+        epilogue_rows<T, NT, STATS, 0, 4 * NT, ACT>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc,
+                                                    (int64_t)z * strideC + yoff, (uint32_t)(mt * kBM + wm * 64 + frow), nb,
+                                                    ep.act_scale, ep.act_shift, ep.act_slope, ep.raw);
     };
 
     const int nk = (gp.Ktot + KSTEP - 1) / KSTEP;
@@ -623,7 +625,7 @@ conv_ntp_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
 // issued two K-steps before they are read: the wait before a K-step's barrier covers the next
 // stage only, the one after it stays in flight across the barrier.  The K-steps of consecutive
 // tiles form one stream, so the ring never drains between tiles.
-template <typename T, int BN, int GM, bool STATS>            // GM: 0 plain gather, 1 upsampling gather, 2 second source
+template <typename T, int BN, int GM, int EPI>               // GM: 0 plain gather, 1 upsampling gather, 2 second source; EPI: 0 plain, 1 statistics, 2 fused normalise
 __global__ void __launch_bounds__(512, 1)
 conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w, int N, int ldw, int ldc,
                      Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, int row_tiles,
@@ -637,6 +639,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     constexpr int A_BYTES = BM * kRowBytes;
     constexpr int B_BYTES = BN * kRowBytes;
     constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr bool STATS = EPI == 1, ACT = EPI == 2;
     constexpr int NT = BN / 32;                           // 16-wide channel tiles per wave
     constexpr int CPL = 4 * NT;                           // consecutive output channels per lane
     using Frag = typename ElemTraits<T>::Frag;
@@ -849,8 +852,9 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     };
     auto write_tile = [&](int row_tile) {
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
-        epilogue_rows<T, NT, STATS_REG>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC + yoff,
-                                        (uint32_t)(mt * BM + wm * 64 + frow), nb);
+        epilogue_rows<T, NT, STATS_REG, 0, 4 * NT, ACT>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc,
+                                                        (int64_t)z * strideC + yoff, (uint32_t)(mt * BM + wm * 64 + frow), nb,
+                                                        ep.act_scale, ep.act_shift, ep.act_slope, ep.raw);
     };
 
     // the 256-channel tile: the lane's 32 channels in two halves, so that only 16 sums and one half's
@@ -861,9 +865,9 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         float t1[16], t2[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
-        epilogue_rows<T, NT, STATS_LDS, (NT == 8 ? 16 * H : 0), (NT == 8 ? 16 : 4 * NT)>(
+        epilogue_rows<T, NT, STATS_LDS, (NT == 8 ? 16 * H : 0), (NT == 8 ? 16 : 4 * NT), ACT>(
             acc, t1, t2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC + yoff,
-            (uint32_t)(mt * BM + wm * 64 + frow), nb);
+            (uint32_t)(mt * BM + wm * 64 + frow), nb, ep.act_scale, ep.act_shift, ep.act_slope, ep.raw);
         if constexpr (STATS_LDS) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -1063,12 +1067,13 @@ constexpr int kHaloRows = 344;                             // 10 x 34 = 340 (or 
 constexpr int kHaloBuf = kHaloRows * 128;
 constexpr int halo_lds_bytes(int ntaps) { return ntaps * 64 * 128 + 2 * kHaloBuf; }   // resident filter + two patches
 
-template <bool STATS, int KR, int KS>
+template <int EPI, int KR, int KS>                          // EPI: 0 plain, 1 statistics, 2 fused normalise
 __global__ void __launch_bounds__(512, 1)
 conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, Epilogue ep,
                      void* __restrict__ yout) {
     using T = bf16_t;
     using Frag = bf16x8_t;
+    constexpr bool STATS = EPI == 1, ACT = EPI == 2;
     constexpr int NT = 2, CPL = 8, NTAPS = KR * KS;
     const int N = ha.N;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1238,6 +1243,15 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
             Vec16<T> ov;
 #pragma unroll
             for (int e = 0; e < CPL; ++e) ov.v[e] = from_f<T>(v[e]);
+            if constexpr (ACT) {                          // the consumer's eval-mode normalise + LeakyReLU of the rounded value
+                if (ep.raw) *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(ep.raw) + offs[i]) = ov;
+                const float4 a0 = *reinterpret_cast<const float4*>(ep.act_scale + nb), a1 = *reinterpret_cast<const float4*>(ep.act_scale + nb + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(ep.act_shift + nb), b1 = *reinterpret_cast<const float4*>(ep.act_shift + nb + 4);
+                const float asc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float ash[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) ov.v[e] = from_f<T>(leaky(fmaf(to_f(ov.v[e]), asc[e], ash[e]), ep.act_slope));
+            }
             *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + offs[i]) = ov;
             if constexpr (STATS) {                        // statistics of the rounded values a later pass would read
 #pragma unroll
@@ -1766,6 +1780,9 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
             if (!configured_w) {
                 int rc = set_lds_limit(conv_ntw_mfma_kernel<T, BN, UP, false>, LDS_W, "conv_ntw_mfma");
                 if (!rc) rc = set_lds_limit(conv_ntw_mfma_kernel<T, BN, UP, true>, LDS_W, "conv_ntw_mfma");
+                if constexpr (UP == 0) {
+                    if (!rc) rc = set_lds_limit(conv_ntw_mfma_kernel<T, BN, UP, 2>, LDS_W, "conv_ntw_mfma");
+                }
                 if (rc) return rc;
                 configured_w = true;
             }
@@ -1778,7 +1795,13 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
                 for (int c = 0; c < cs.ncls; ++c) cs.stats_off[c] = (int64_t)(cs.first_block[c] / n_tiles) * N * 2;
             }
             TimedLaunch timed(TIMED_NT, take_flops(flops), flops, st);
-            if (ep.stats)
+            if (ep.act_scale) {
+                if constexpr (UP == 0)
+                    hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, 2>), dim3(blocks), dim3(512), LDS_W, st, gp,
+                                       x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
+                else
+                    return fail(VAMD_EUNSUPPORTED, "conv_ntw_mfma: fused normalise with this gather");
+            } else if (ep.stats)
                 hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, BN, UP, true>), dim3(blocks), dim3(512), LDS_W, st, gp,
                                    x, w, N, ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
             else
@@ -1792,6 +1815,9 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
     if (!configured_p) {
         int rc = set_lds_limit(conv_ntp_mfma_kernel<T, BN, UP, false>, LDS_PIPE, "conv_ntp_mfma");
         if (!rc) rc = set_lds_limit(conv_ntp_mfma_kernel<T, BN, UP, true>, LDS_PIPE, "conv_ntp_mfma");
+        if constexpr (UP == 0) {
+            if (!rc) rc = set_lds_limit(conv_ntp_mfma_kernel<T, BN, UP, 2>, LDS_PIPE, "conv_ntp_mfma");
+        }
         if (rc) return rc;
         configured_p = true;
     }
@@ -1804,7 +1830,13 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
         for (int c = 0; c < cs.ncls; ++c) cs.stats_off[c] = (int64_t)(cs.first_block[c] / n_tiles) * N * 2;
     }
     TimedLaunch timed(TIMED_NT, take_flops(flops), flops, st);
-    if (ep.stats)
+    if (ep.act_scale) {
+        if constexpr (UP == 0)
+            hipLaunchKernelGGL((conv_ntp_mfma_kernel<T, BN, UP, 2>), dim3(blocks), dim3(256), LDS_PIPE, st, gp, x,
+                               w, N, ldw, ldc, ep, y, m_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
+        else
+            return fail(VAMD_EUNSUPPORTED, "conv_ntp_mfma: fused normalise with this gather");
+    } else if (ep.stats)
         hipLaunchKernelGGL((conv_ntp_mfma_kernel<T, BN, UP, true>), dim3(blocks), dim3(256), LDS_PIPE, st, gp, x,
                            w, N, ldw, ldc, ep, y, m_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
     else
@@ -1834,6 +1866,9 @@ static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ld
     if (!configured) {
         int rc = set_lds_limit(conv_ntw_mfma_kernel<T, 256, UP, false>, LDS_W, "conv_ntw_mfma");
         if (!rc) rc = set_lds_limit(conv_ntw_mfma_kernel<T, 256, UP, true>, LDS_W, "conv_ntw_mfma");
+        if constexpr (UP == 0) {
+            if (!rc) rc = set_lds_limit(conv_ntw_mfma_kernel<T, 256, UP, 2>, LDS_W, "conv_ntw_mfma");
+        }
         if (rc) return rc;
         configured = true;
     }
@@ -1843,7 +1878,13 @@ static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ld
     TimedLaunch timed(TIMED_NT, take_flops(2.0 * gp.M * N * gp.Ktot * batch), 2.0 * gp.M * N * gp.Ktot * batch, st);
     ClassSet cs;
     cs.ncls = 0;
-    if (ep.stats)
+    if (ep.act_scale) {
+        if constexpr (UP == 0)
+            hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, 256, UP, 2>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp, x, w, N,
+                               ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
+        else
+            return fail(VAMD_EUNSUPPORTED, "conv_ntw_mfma: fused normalise with this gather");
+    } else if (ep.stats)
         hipLaunchKernelGGL((conv_ntw_mfma_kernel<T, 256, UP, true>), dim3(groups * n_tiles), dim3(512), LDS_W, st, gp, x, w, N,
                            ldw, ldc, ep, y, mw_tiles, n_tiles, row_tiles, sA, sB, sC, cs);
     else
@@ -1889,12 +1930,14 @@ static int launch_c64_halo(const HaloArgs& ha, const bf16_t* x, const bf16_t* w,
     if (!configured) {
         int rc = set_lds_limit(conv_c64_halo_kernel<false, KR, KS>, LDS, "conv_c64_halo");
         if (!rc) rc = set_lds_limit(conv_c64_halo_kernel<true, KR, KS>, LDS, "conv_c64_halo");
+        if (!rc) rc = set_lds_limit(conv_c64_halo_kernel<2, KR, KS>, LDS, "conv_c64_halo");
         if (rc) return rc;
         configured = true;
     }
     const int blocks = c64_halo_blocks(ha.ntiles, ha.n_tiles * ha.ncls);
     TimedLaunch timed(TIMED_NT, take_flops(flops), flops, st);
-    if (ep.stats) hipLaunchKernelGGL((conv_c64_halo_kernel<true, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
+    if (ep.act_scale) hipLaunchKernelGGL((conv_c64_halo_kernel<2, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
+    else if (ep.stats) hipLaunchKernelGGL((conv_c64_halo_kernel<true, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
     else hipLaunchKernelGGL((conv_c64_halo_kernel<false, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
     VAMD_LAUNCH_OK("conv_c64_halo");
     return 0;
@@ -1983,6 +2026,12 @@ splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int64_t MN, int
             Vec16<T> ov;
 #pragma unroll
             for (int e = 0; e < PIECE; ++e) ov.v[e] = from_f<T>(v[e]);
+            if (ep.act_scale) {                          // the consumer's eval-mode normalise + LeakyReLU of the rounded value
+                if (ep.raw) *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(ep.raw) + off) = ov;
+#pragma unroll
+                for (int e = 0; e < PIECE; ++e)
+                    ov.v[e] = from_f<T>(leaky(fmaf(to_f(ov.v[e]), ep.act_scale[n + e], ep.act_shift[n + e]), ep.act_slope));
+            }
             *reinterpret_cast<Vec16<T>*>(y + off) = ov;
             if constexpr (STATS) {
 #pragma unroll
@@ -2129,6 +2178,21 @@ int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, co
                   const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st) {
     Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
     Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats, (unsigned char*)g.scratch, g.scratch_bytes};
+    if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
+    return run_nt<float>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
+}
+
+// The forward with the consumer's eval-mode BatchNorm + LeakyReLU folded into the epilogue.  Kernels that implement
+// it: the persistent 4-wave kernels on plain gathers, the resident-filter kernel and the split reduction.
+bool conv_fwd_act_mfma_supported(const ConvGeom& g, int dtype) {
+    return !nt_classic() && !g.up && nt_shape_ok(g.Cin, g.Cout, g.M, dtype) && g.Cout % (dtype == VAMD_BF16 ? 8 : 4) == 0;
+}
+
+int conv_fwd_act_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias, const float* temb,
+                      const void* res, const void* res2, const float* scale, const float* shift, float slope, void* y,
+                      void* raw, hipStream_t st) {
+    Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
+    Epilogue ep{bias, temb, res, res2, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes, scale, shift, slope, raw};
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
     return run_nt<float>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
 }
@@ -2392,12 +2456,14 @@ bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype) {
     return tn_shape_ok(g.Cin, g.Cout, g.M, dtype);
 }
 
-// Pixel slices of the weight gradient: one workgroup per CU-slot when the filter has few tiles (each
-// slice then runs longer and the partial buffer stays small), two rounds' worth when it has many;
-// at least 8 K-steps per slice, every slice non-empty.
+// Pixel slices of the weight gradient: two workgroups per CU in all (each slice runs long and the partial buffer
+// stays small); at least 8 K-steps per slice, every slice non-empty.
 static int tn_slice_cap(int tiles) {
     static const int v = [] { const char* e = getenv("VAMD_TN_BLOCKS"); return e ? atoi(e) : 0; }();
-    return v > 0 ? v : (tiles >= 64 ? 1024 : 512);
+    // 512 for every filter: in the step it equals a cap of 1024 for many-tile filters at 64 images (19.49 / 19.51 ms)
+    // and is ahead at 16 (8.06 -> 7.96 ms: fewer slices to write and add); 256 and 768+ lose 4-15 %
+    (void)tiles;
+    return v > 0 ? v : 512;
 }
 static void tn_split(int tiles, int total_steps, int* slices_out, int* steps_per_out) {
     int slices = tn_slice_cap(tiles) / tiles;

@@ -492,6 +492,7 @@ bool nt8_applicable(const Gather& gp, int N, int ldw, int ldc, const Epilogue& e
     // here reach the epilogue of their 128 x 64 wave tiles together and wait for the terms' loads with no MFMA
     // work left to cover them.
     static const int with_terms = nt8_env("VAMD_NT8_TERMS", 0);
+    if (ep.act_scale) return false;                          // the fused normalise lives in the 4-wave kernels
     if (!with_terms && (ep.temb || ep.res || ep.res2 || ep.stats)) return false;
     static const int wide_k = nt8_env("VAMD_NT8_WIDE_K", 1152);
     if (nt8_tile(N) == 256 && gp.Ktot > wide_k) return false;

@@ -69,6 +69,13 @@ struct Epilogue {
     float* stats;          // [row tiles][N][2]: per row tile, column sums of the stored y and y*y (or NULL)
     unsigned char* scratch;   // caller's scratch buffer for partial sums of split tiles (or NULL)
     size_t scratch_bytes;
+    // Eval-mode BatchNorm + LeakyReLU of the consumer folded into this launch (act_scale != NULL): the stored value
+    // becomes round(leaky(fma(q, act_scale[n], act_shift[n]))) with q the rounded convolution output -- bit for bit
+    // what a separate normalise pass over the stored q would write -- and q itself goes to `raw` if that is given.
+    const float* act_scale;
+    const float* act_shift;
+    float act_slope;
+    void* raw;
 };
 
 // Up to four convolutions of one layer in one launch (the output-parity classes of a stride-2 input
@@ -128,11 +135,13 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 // re-initialised for the next tile anyway; the order of the additions is temb, res, res2.
 // Core: the four rows are given by the element offset of the lane's first channel (offs), the image
 // each belongs to (bimg, for the time embedding; ascending) and a validity flag.
-template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT>
+template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT, bool ACT = false>
 __device__ __forceinline__ void epilogue_rows_at(f32x4_t (&acc)[NT][4], float* s1, float* s2,
                                                  const float* temb, const void* res, const void* res2, float alpha,
                                                  int out_f32, void* yout, int N, int ldc, const int64_t (&offs)[4],
-                                                 const uint32_t (&bimg)[4], const bool (&valid)[4], int nb) {
+                                                 const uint32_t (&bimg)[4], const bool (&valid)[4], int nb,
+                                                 const float* asc = nullptr, const float* ash = nullptr,
+                                                 float aslope = 0.f, void* raw = nullptr) {
     static_assert(C0 % 8 == 0 && CW % 8 == 0 && C0 + CW <= 4 * NT, "whole 16-byte pieces of the lane's channels");
     constexpr int CH = 16 / (int)sizeof(T);               // channels per 16-byte piece of T: 8 (bf16) or 4
     constexpr int NP = CW / CH;                           // pieces per row and lane
@@ -230,6 +239,32 @@ __device__ __forceinline__ void epilogue_rows_at(f32x4_t (&acc)[NT][4], float* s
                     for (int e = 0; e < CH; ++e) acc[J0 + ((p * CH + e) >> 2)][i][e & 3] += to_f(rv[i][p].v[e]);
                 }
     }
+    if constexpr (ACT) {                                  // piece by piece, so that only one piece's coefficients are live
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (!piece_ok[p]) continue;
+            float sc[CH], sh[CH];
+#pragma unroll
+            for (int e = 0; e < CH; e += 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(asc + nb + p * CH + e);
+                const float4 b4 = *reinterpret_cast<const float4*>(ash + nb + p * CH + e);
+                sc[e] = a4.x; sc[e + 1] = a4.y; sc[e + 2] = a4.z; sc[e + 3] = a4.w;
+                sh[e] = b4.x; sh[e + 1] = b4.y; sh[e + 2] = b4.z; sh[e + 3] = b4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!valid[i]) continue;
+                Vec16<T> ov;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(acc[J0 + ((p * CH + e) >> 2)][i][e & 3]);
+                if (raw) *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(raw) + offs[i] + p * CH) = ov;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(leaky(fmaf(to_f(ov.v[e]), sc[e], sh[e]), aslope));
+                *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + offs[i] + p * CH) = ov;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (!valid[i]) continue;
@@ -253,11 +288,12 @@ __device__ __forceinline__ void epilogue_rows_at(f32x4_t (&acc)[NT][4], float* s
 }
 
 // The same for rows m_first + 16*i of the GEMM (with the output scatter of a parity class, if any).
-template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT>
+template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT, bool ACT = false>
 __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[NT][4], float* s1, float* s2, const Gather& gp,
                                               const float* temb, const void* res, const void* res2, float alpha,
                                               int out_f32, void* yout, int N, int ldc, int64_t zoff,
-                                              uint32_t m_first, int nb) {
+                                              uint32_t m_first, int nb, const float* asc = nullptr,
+                                              const float* ash = nullptr, float aslope = 0.f, void* raw = nullptr) {
     nb += C0;
     int64_t offs[4];
     uint32_t bimg[4];
@@ -279,7 +315,8 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[NT][4], float* s1, 
         }
         offs[i] = zoff + orow * ldc + nb;
     }
-    epilogue_rows_at<T, NT, STATS, C0, CW>(acc, s1, s2, temb, res, res2, alpha, out_f32, yout, N, ldc, offs, bimg, valid, nb);
+    epilogue_rows_at<T, NT, STATS, C0, CW, ACT>(acc, s1, s2, temb, res, res2, alpha, out_f32, yout, N, ldc, offs, bimg, valid, nb,
+                                                asc, ash, aslope, raw);
 }
 
 // Ping-pong kernel for the wide bf16 layers (conv_nt8.hip): 256 x 256 or 512 x 128 tiles, plain gathers only.

@@ -53,6 +53,10 @@ int thin_wgrad_mfma(const ConvGeom& g, const void* dy, const void* x, float* dw,
 
 // MFMA implicit-GEMM kernels (conv_mfma.hip).  *_supported says whether the shape is covered.
 bool conv_fwd_mfma_supported(const ConvGeom& g, int dtype);
+bool conv_fwd_act_mfma_supported(const ConvGeom& g, int dtype);
+int conv_fwd_act_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias, const float* temb,
+                      const void* res, const void* res2, const float* scale, const float* shift, float slope, void* y,
+                      void* raw, hipStream_t st);
 int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, const float* bias,
                   const float* temb, const void* res, const void* res2, void* y, float* stats, hipStream_t st);
 int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype);      // row tiles = leading extent of `stats`

@@ -206,7 +206,9 @@ class DDPMModel(LightningModule):
         return m
 
     def _anchor(self):
-        return self.linear_1.weight
+        """The parameter through which autograd reaches the engine's backward.  Without grad mode it is handed over
+        detached: Function.forward then sees that no backward can follow and keeps no tape (validation, sampling)."""
+        return self.linear_1.weight if torch.is_grad_enabled() else self.linear_1.weight.detach()
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)

@@ -127,6 +127,25 @@ class _Conv:
             e.stats_for[y.data_ptr()] = (part, nparts)
         return y
 
+    def fwd_act(self, x, norm, temb=None, res=None, res2=None, want_raw=False):
+        """conv(x) + bias (+ temb + res + res2) with the eval-mode BatchNorm `norm` + LeakyReLU of the consumer applied in
+        the same launch: returns (activated, raw output or None), or None when no kernel covers the shape.  Bit-identical
+        to fwd() followed by norm.fwd(..., training=False)."""
+        B, H, W, _ = x.shape
+        d = self.desc(B, H, W)
+        if self.up or not lib.vamd_conv2d_fwd_act_supported(C.byref(d)):
+            return None
+        Ho, Wo = self.out_hw(H, W)
+        coef = norm.eval_coef()
+        y = torch.empty((B, Ho, Wo, self.cout), dtype=self.eng.dtype, device=x.device)
+        raw = torch.empty_like(y) if want_raw else None
+        ev = self._timed(0, B, H, W)
+        call("vamd_conv2d_fwd_act", C.byref(d), _ptr(x), _ptr(self.wf), _ptr(self.b), _ptr(temb), _ptr(res), _ptr(res2),
+             _ptr(coef[0]), _ptr(coef[1]), norm.slope, _ptr(y), _ptr(raw), _stream())
+        if ev is not None:
+            ev.record()
+        return y, raw
+
     def fwd_short(self, x, short, x2, res2=None, bias_sum=None, want_stats=False):
         """y = conv(x) + short(x2) + (both biases) (+ res2) in one launch (`short` is a 1x1 _Conv whose
         output has this conv's shape), or None when the kernels do not cover the shape."""
@@ -205,6 +224,8 @@ class _Linear:
 
 
 FUSE_SHORTCUT = os.environ.get("VAMD_FWD_SHORT", "0") != "0"
+# eval-mode forward without a tape (the sampler): BatchNorm + LeakyReLU applied by the producing convolution's epilogue
+FUSE_EVAL_NORM = os.environ.get("VAMD_EVAL_FUSE", "1") != "0"
 
 
 class _Norm:
@@ -220,24 +241,29 @@ class _Norm:
         self.slope = LEAKY_SLOPE if batchnorm else 1.0
         self._eval_coef, self._eval_key = None, None
 
+    def eval_coef(self):
+        """(scale, shift, mean, rstd) [4][1][C] of an eval-mode BatchNorm: they depend on parameters and running
+        statistics only, so they are kept until either changes (a sampler asks once per denoising step)."""
+        e = self.eng
+        key = (e.coef_epoch, e.flat_b._version)
+        if self._eval_coef is None or self._eval_key != key:
+            coef = torch.empty((4, 1, self.C), dtype=torch.float32, device=e.device)
+            call("vamd_bn_finalize", None, 0, self.C, 0, _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm),
+                 _ptr(self.rv), None, BN_MOMENTUM, BN_EPS, 0, _ptr(coef[0]), _ptr(coef[1]), _ptr(coef[2]), _ptr(coef[3]),
+                 _stream())
+            self._eval_coef, self._eval_key = coef, key
+        return self._eval_coef
+
     def fwd(self, x, training, mask=None, mask_scale=1.0):
         B, H, W, Cc = x.shape
         e, dev = self.eng, x.device
         G, R = (1, B * H * W) if self.bn else (B, H * W)
-        coef = torch.empty((4, G, Cc), dtype=torch.float32, device=dev)   # scale, shift, mean, rstd
-        sc, sh, mu, rs = coef[0], coef[1], coef[2], coef[3]
         if self.bn and not training:
-            # eval mode: the coefficients depend on parameters and running statistics only, so they are
-            # kept until either changes (a sampler calls this once per denoising step)
-            key = (e.coef_epoch, e.flat_b._version)
-            if self._eval_coef is not None and self._eval_key == key:
-                coef = self._eval_coef
-                sc, sh = coef[0], coef[1]
-            else:
-                call("vamd_bn_finalize", None, 0, Cc, 0, _ptr(self.gamma), _ptr(self.beta), _ptr(self.rm),
-                     _ptr(self.rv), None, BN_MOMENTUM, BN_EPS, 0, _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs), _stream())
-                self._eval_coef, self._eval_key = coef, key
+            coef = self.eval_coef()
+            sc, sh = coef[0], coef[1]
         else:
+            coef = torch.empty((4, G, Cc), dtype=torch.float32, device=dev)   # scale, shift, mean, rstd
+            sc, sh, mu, rs = coef[0], coef[1], coef[2], coef[3]
             fused = e.stats_for.pop(x.data_ptr(), None) if self.bn else None
             if fused is not None:                 # the producing convolution already summed y and y*y
                 part, nchunk = fused
@@ -323,12 +349,29 @@ class _ResBlock:
         if self.bsum is not None:
             torch.add(self.conv2.b, self.short.b, out=self.bsum)
 
-    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
-        a1, coef1 = self.bn1.fwd(x, training)
+    def final_conv(self):
+        return self.conv2
+
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False, next_norm=None):
+        fuse = FUSE_EVAL_NORM and not training and tape is None
+        a1 = self.eng.act_for.pop(x.data_ptr(), None) if fuse else None   # left by the producer of x, if it could
+        coef1 = None
+        if a1 is None:
+            a1, coef1 = self.bn1.fwd(x, training)
         # projected with the other blocks' in one launch, if this is the embedding that launch projected
         tproj = self.eng.tproj_for.get(id(self)) if self.eng.tproj_src is temb else None
         if tproj is None:
             tproj = self.temb.fwd(temb)
+        if fuse:
+            sc = self.short.fwd(x) if self.short is not None else x
+            # no tape: h1 itself is never needed, its normalised form comes straight out of conv1
+            got = self.conv1.fwd_act(a1, self.bn2, temb=tproj)
+            a2 = got[0] if got is not None else self.bn2.fwd(self.conv1.fwd(a1, temb=tproj), False)[0]
+            got = self.conv2.fwd_act(a2, next_norm, res=sc, res2=res2, want_raw=True) if next_norm is not None else None
+            if got is None:
+                return self.conv2.fwd(a2, res=sc, res2=res2)
+            self.eng.act_for[got[1].data_ptr()] = got[0]
+            return got[1]
         h1 = self.conv1.fwd(a1, temb=tproj, want_stats=training)
         mask = None
         if training and self.spec.dropout > 0.0:
@@ -405,7 +448,7 @@ class _AttnBlock:
         call("vamd_transpose", _ptr(t), _ptr(out), batch, R, Cc, ld, self.eng.dt, _stream())
         return out
 
-    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False, next_norm=None):
         B, H, W, Cc = x.shape
         S = H * W
         Sp = (S + 7) // 8 * 8
@@ -419,6 +462,10 @@ class _AttnBlock:
         vT = self._transpose_padded(v, B, S, Cc, Sp)                          # [B][C][Sp]
         o = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)             # o[s][c] = sum_t P[s][t] v[t][c]
         self._bmm_nt(P, vT, o, B, S, Cc, S, Sp, Sp, Cc, 1.0)
+        got = self.o.fwd_act(o, next_norm, res=x, res2=res2, want_raw=True) if next_norm is not None else None
+        if got is not None:                       # the next block's eval-mode BatchNorm rides on the output projection
+            e.act_for[got[1].data_ptr()] = got[0]
+            return got[1]
         y = self.o.fwd(o, res=x, res2=res2, want_stats=want_stats)
         if tape is not None:
             tape.append((self, (x, hn, coef, q, k, v, P, o)))
@@ -479,8 +526,12 @@ class _Resample:
         call("vamd_unpool2x2", _ptr(x), _ptr(add), _ptr(y), B, Hs, Ws, Cc, H, W, scale, self.eng.dt, _stream())
         return y
 
-    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False):
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False, next_norm=None):
         if self.conv is not None:
+            got = self.conv.fwd_act(x, next_norm, res2=res2, want_raw=True) if next_norm is not None else None
+            if got is not None:
+                self.eng.act_for[got[1].data_ptr()] = got[0]
+                return got[1]
             y = self.conv.fwd(x, res2=res2, want_stats=want_stats)
         elif self.down:
             y = self._pool(x, res2, 0.25)
@@ -509,6 +560,7 @@ class Engine:
         self.device = params[0][1].device
         self.plan, self.dtype, self.algo = plan, dtype, algo
         self.stats_for: Dict[int, tuple] = {}      # output data_ptr -> (partial sums, parts) left by a conv epilogue
+        self.act_for: Dict[int, torch.Tensor] = {}  # output data_ptr -> its eval-mode normalised form (same launch)
         # zero-filled once, then owned by the kernels (flags and partial sums of tiles split between workgroups)
         # (partial products of layers whose reduction is split between workgroups: the small, deep layers)
         self.scratch = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=self.device)
@@ -692,6 +744,7 @@ class Engine:
         Returns the NHWC prediction; if `tape` is a list it receives what backward needs."""
         self.refresh()
         self.stats_for.clear()
+        self.act_for.clear()
         if training:
             self.coef_epoch += 1                              # running statistics are about to change
         B = x.shape[0]
@@ -717,7 +770,10 @@ class Engine:
             # a train-mode ResBlock next: its first BatchNorm takes its statistics from this layer's epilogue
             nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
             want = training and isinstance(nxt, _ResBlock)
-            h = layer.fwd(h, temb, training, res2, tape, drop_masks.get(layer.spec.prefix), want_stats=want)
+            # an eval-mode ResBlock next and no backward to follow: its first BatchNorm + LeakyReLU is applied by this
+            # layer's last convolution, which then writes both the plain output and the normalised one
+            nn_ = nxt.bn1 if (FUSE_EVAL_NORM and not training and tape is None and isinstance(nxt, _ResBlock)) else None
+            h = layer.fwd(h, temb, training, res2, tape, drop_masks.get(layer.spec.prefix), want_stats=want, next_norm=nn_)
             if self.debug_taps is not None:
                 self.debug_taps[layer.spec.prefix] = (h, res2)
             if i < nd:
