@@ -296,6 +296,14 @@ int vamd_unpool2x2(const void* x, const void* add, void* y, int B, int Hs, int W
                    void* stream);
 /* x [batch][R][C] -> y [batch][C][ldy] (ldy >= R; padding columns are left untouched). */
 int vamd_transpose(const void* x, void* y, int batch, int R, int C, int ldy, int dtype, void* stream);
+/* The attention core of AttnBlock.forward (reference models/ddpm.py:113-120) in one kernel, bf16: o = softmax(q k^T *
+ * scale) v per image; q, k: [B][S][C]; vT: the values transposed, [B][C][ldv] (ldv >= S, a multiple of 8; columns past
+ * S are not read); o: [B][S][C].  S <= 1024, C a multiple of 32 up to 512 (vamd_attention_fwd_supported).  The S x S
+ * scores and probabilities stay on chip; a backward pass needs the probabilities and therefore the separate
+ * vamd_bmm_nt / vamd_softmax_rows calls. */
+int vamd_attention_fwd_supported(int S, int C, int dtype);
+int vamd_attention_fwd(const void* q, const void* k, const void* vT, void* o, int B, int S, int C, int ldv, float scale,
+                       int dtype, void* stream);
 /* Row softmax over the first `cols` entries of rows of stride ld (F.softmax, models/ddpm.py:118)
  * and its gradient ds = alpha * p * (dp - sum(dp * p)).  x and dp are fp32, p and ds are `dtype`. */
 int vamd_softmax_rows(const float* x, void* y, int64_t rows, int cols, int ld, int dtype,

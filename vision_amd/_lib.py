@@ -116,6 +116,8 @@ SIGNATURES = {
     "vamd_pool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "vamd_unpool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "vamd_transpose": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_attention_fwd_supported": (_i, [_i, _i, _i]),
+    "vamd_attention_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "vamd_softmax_rows": (_i, [_p, _p, _l, _i, _i, _i, _p]),
     "vamd_softmax_rows_bwd": (_i, [_p, _p, _p, _l, _i, _i, _f, _i, _p]),
     "vamd_add": (_i, [_p, _p, _p, _l, _i, _p]),

@@ -226,6 +226,10 @@ class _Linear:
 FUSE_SHORTCUT = os.environ.get("VAMD_FWD_SHORT", "0") != "0"
 # eval-mode forward without a tape (the sampler): BatchNorm + LeakyReLU applied by the producing convolution's epilogue
 FUSE_EVAL_NORM = os.environ.get("VAMD_EVAL_FUSE", "1") != "0"
+# forwards without a tape: the attention core as one kernel (bf16, S <= 1024, C <= 512), bit-identical to the three
+# separate kernels and without their S x S tensors in HBM.  Opt-in: measured 10-40 % slower than the three MFMA kernels
+# at the sizes of the shipped configs (4 x 1024 x 256: 62 vs 49 us; 64 x 196 x 512: 95 vs 52 us; -0.7 % on ffhq sampling)
+FUSE_ATTENTION = os.environ.get("VAMD_ATTN_FUSE", "0") != "0"
 
 
 class _Norm:
@@ -455,6 +459,16 @@ class _AttnBlock:
         e, dev = self.eng, x.device
         hn, coef = self.norm.fwd(x, training)
         q, k, v = self.q.fwd(hn), self.k.fwd(hn), self.v.fwd(hn)
+        if tape is None and FUSE_ATTENTION and lib.vamd_attention_fwd_supported(S, Cc, e.dt):
+            # no backward to follow: scores, softmax and the product with the values in one kernel, nothing S x S in HBM
+            vT = self._transpose_padded(v, B, S, Cc, Sp)
+            o = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)
+            call("vamd_attention_fwd", _ptr(q), _ptr(k), _ptr(vT), _ptr(o), B, S, Cc, Sp, Cc ** -0.5, e.dt, _stream())
+            got = self.o.fwd_act(o, next_norm, res=x, res2=res2, want_raw=True) if next_norm is not None else None
+            if got is not None:
+                e.act_for[got[1].data_ptr()] = got[0]
+                return got[1]
+            return self.o.fwd(o, res=x, res2=res2)
         scores = torch.empty((B, S, Sp), dtype=torch.float32, device=dev)     # [B][query][key]
         self._bmm_nt(q, k, scores, B, S, S, Cc, Cc, Cc, Sp, Cc ** -0.5)
         P = torch.zeros((B, S, Sp), dtype=e.dtype, device=dev)
