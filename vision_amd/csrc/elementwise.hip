@@ -472,16 +472,44 @@ repack_weights_kernel(const vamd_repack_item* __restrict__ items, int n) {
         tile[ol][rem] = (o < O && i < I) ? w[((int64_t)o * I + i0) * kk + rem] : 0.f;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < TO * run; idx += 256) {          // wf[o][tap][i]
-        const int il = idx % TI, tap = (idx / TI) % kk, ol = idx / run;
-        const int o = o0 + ol, i = i0 + il;
-        if (o < O && i < I) wf[((int64_t)o * kk + tap) * I + i] = from_f<T>(tile[ol][il * kk + tap]);
+    // two consecutive elements per thread and store where the channel counts are even (all but the 3-channel edges)
+    const bool pair_i = (I & 1) == 0, pair_o = (O & 1) == 0;
+    if (pair_i) {
+        for (int idx = threadIdx.x; idx < TO * run / 2; idx += 256) {  // wf[o][tap][i], i in pairs
+            const int il = (idx % (TI / 2)) * 2, tap = (idx / (TI / 2)) % kk, ol = idx / (run / 2);
+            const int o = o0 + ol, i = i0 + il;
+            if (o < O && i < I) {
+                T two[2] = {from_f<T>(tile[ol][il * kk + tap]), from_f<T>(tile[ol][(il + 1) * kk + tap])};
+                T* dst = wf + ((int64_t)o * kk + tap) * I + i;
+                if (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(two);
+                else *reinterpret_cast<uint64_t*>(dst) = *reinterpret_cast<const uint64_t*>(two);
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < TO * run; idx += 256) {      // wf[o][tap][i]
+            const int il = idx % TI, tap = (idx / TI) % kk, ol = idx / run;
+            const int o = o0 + ol, i = i0 + il;
+            if (o < O && i < I) wf[((int64_t)o * kk + tap) * I + i] = from_f<T>(tile[ol][il * kk + tap]);
+        }
     }
     if (!wd) return;
-    for (int idx = threadIdx.x; idx < TO * run; idx += 256) {          // wd[i][flipped tap][o]
-        const int ol = idx % TO, tap = (idx / TO) % kk, il = idx / (TO * kk);
-        const int o = o0 + ol, i = i0 + il;
-        if (o < O && i < I) wd[((int64_t)i * kk + (kk - 1 - tap)) * O + o] = from_f<T>(tile[ol][il * kk + tap]);
+    if (pair_o) {
+        for (int idx = threadIdx.x; idx < TO * run / 2; idx += 256) {  // wd[i][flipped tap][o], o in pairs
+            const int ol = (idx % (TO / 2)) * 2, tap = (idx / (TO / 2)) % kk, il = idx / (TO / 2 * kk);
+            const int o = o0 + ol, i = i0 + il;
+            if (o < O && i < I) {
+                T two[2] = {from_f<T>(tile[ol][il * kk + tap]), from_f<T>(tile[ol + 1][il * kk + tap])};
+                T* dst = wd + ((int64_t)i * kk + (kk - 1 - tap)) * O + o;
+                if (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(two);
+                else *reinterpret_cast<uint64_t*>(dst) = *reinterpret_cast<const uint64_t*>(two);
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < TO * run; idx += 256) {      // wd[i][flipped tap][o]
+            const int ol = idx % TO, tap = (idx / TO) % kk, il = idx / (TO * kk);
+            const int o = o0 + ol, i = i0 + il;
+            if (o < O && i < I) wd[((int64_t)i * kk + (kk - 1 - tap)) * O + o] = from_f<T>(tile[ol][il * kk + tap]);
+        }
     }
 }
 
