@@ -160,7 +160,7 @@ def test_ffhq_plan_matches_reference_module_sequence():
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_ffhq_wiring_against_oracle(mode):
     """Tolerances as for the 224x224 model (test_full_size_gpu.test_full_resolution_model_against_oracle):
-    prediction 2e-6 / 2e-2, loss 1e-5 / 2e-2, global gradient error 2e-3 / 5e-2 (fp32 / bf16 compute)."""
+    prediction 2e-6 / 2e-2, loss 1e-5 / 2e-2, global gradient error 1.5e-3 / 4.5e-2 (fp32 / bf16 compute; twice the measured)."""
     model, cfg, sd, R = _ffhq_small(mode)
     model.train()
     g = torch.Generator().manual_seed(3)
@@ -183,7 +183,8 @@ def test_ffhq_wiring_against_oracle(mode):
     want = torch.cat([ref64[n].flatten() for n in names])
     got = torch.cat([p.grad.detach().flatten().double().cpu() for _, p in model.named_parameters()])
     err = ((got - want).norm() / want.norm()).item()
-    assert err < (2e-3 if mode == "fp32" else 5e-2), err
+    print(f"global gradient error, ffhq wiring at 128x128, {mode}: {err:.2e}")
+    assert err < (1.5e-3 if mode == "fp32" else 4.5e-2), err     # measured 7.3e-4 / 2.2e-2
     # eval-mode sampler on the same wiring: 3 steps against the oracle's sampler (from the initial state: the
     # training step above has moved the BatchNorm running statistics)
     model.load_state_dict(sd)

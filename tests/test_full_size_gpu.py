@@ -155,7 +155,7 @@ def _butterfly_model(compute_dtype):
 def test_full_resolution_model_against_oracle(mode, fuse_shortcut, monkeypatch):
     """224x224 butterfly UNet on 2 images against the oracle evaluated in fp64.
     Train-mode prediction: 2e-6 (fp32 compute; torch's own fp32 forward is at 2.4e-7) / 2e-2 (bf16).
-    Loss: 1e-5 / 2e-2.  Gradients, global relative error: 2e-3 / 5e-2 - the L1 loss's sign() turns
+    Loss: 1e-5 / 2e-2.  Gradients, global relative error: 1.4e-3 / 2.2e-2 (twice what is measured) - the L1 loss's sign() turns
     a forward rounding difference of 1e-6 into flipped gradient signs for the outputs that sit
     that close to their target, which costs ~1e-3 of the gradient norm (the oracle's own fp32
     gradient is 7e-5 away from its fp64 gradient); measured 7e-4 / 1.1e-2."""
@@ -185,7 +185,8 @@ def test_full_resolution_model_against_oracle(mode, fuse_shortcut, monkeypatch):
     want = torch.cat([ref64[n].flatten() for n in names])
     got = torch.cat([p.grad.detach().flatten().double().cpu() for _, p in model.named_parameters()])
     err = ((got - want).norm() / want.norm()).item()
-    assert err < (2e-3 if mode == "fp32" else 5e-2), err
+    print(f"global gradient error, 224x224 model, {mode}: {err:.2e}")
+    assert err < (1.4e-3 if mode == "fp32" else 2.2e-2), err
 
 
 def test_full_batch_forward_is_batch_independent_and_step_is_reproducible(no_splitk):

@@ -178,7 +178,10 @@ def test_loss_grads_bnstats(golden, mode):
     ref = sub(g, "grad")
     keys = sorted(e32)
     e_all = rel(_cat(grads, keys), _cat(ref, keys))
-    assert e_all < (2e-2 if dtype == torch.float32 else max(0.1, 2 * ebf_all)), e_all
+    print(f"p_loss gradients vs the reference's fp32 gradients, {name} {mode}: {e_all:.2e} (reference bf16 autocast: {ebf_all:.2e})")
+    # measured: fp32 2.4e-5 ... 1.3e-3 (the larger ones are single L1 sign flips reached through the device-side schedule);
+    # bf16 at most 1.35 x the reference's own bf16 autocast error on the same step
+    assert e_all < (2.6e-3 if dtype == torch.float32 else 1.7 * ebf_all), e_all
     sd = m.state_dict()
     for k, v in sub(g, "bn1").items():
         if v.dtype == torch.int64:

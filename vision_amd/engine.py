@@ -350,7 +350,7 @@ class _ResBlock:
         self.bsum = torch.zeros(spec.cout, dtype=torch.float32, device=eng.device) if self.short is not None else None
 
     def refresh_bias(self):
-        if self.bsum is not None:
+        if self.bsum is not None and FUSE_SHORTCUT:       # only the one-launch form of conv2 + shortcut reads it
             torch.add(self.conv2.b, self.short.b, out=self.bsum)
 
     def final_conv(self):
