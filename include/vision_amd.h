@@ -378,6 +378,22 @@ int vamd_nhwc_to_nchw(const void* x_nhwc, float* y_nchw, int B, int C, int H, in
 int vamd_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                int step, float grad_scale, void* stream);
+/* torch.optim.Adam with weight_decay (models/vqvaeunet.py:263-269): the decay enters the gradient, g + weight_decay * p,
+ * before the moment updates.  Arguments as vamd_adamw. */
+int vamd_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                 const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                 int step, float grad_scale, void* stream);
+
+/* Head and reconstruction loss of the VQ-VAE-UNet first stage (reference models/vqvaeunet.py:206-210 nn.Sigmoid() after
+ * the last channel-wise Linear, :236-240 rec_loss = F.mse_loss(x_rec, x)).
+ * fwd: h [B][H][W][C] in `dtype` -> xrec [B][C][H][W] fp32 = sigmoid(h); with target (the input images, NCHW fp32) also
+ *      loss[0] = mean((xrec - target)^2) through `partial` (vamd_l1_chunks(B*H*W) floats, fixed summation order).
+ * bwd: dh = (g_loss[0] * 2 (xrec - target) / numel + g_xrec) * xrec * (1 - xrec); g_loss (one device float, with
+ *      target) and g_xrec (NCHW fp32) may each be NULL. */
+int vamd_sigmoid_mse_fwd(const void* h, const float* target, float* xrec, float* partial, float* loss, int B, int C, int H,
+                         int W, int dtype, void* stream);
+int vamd_sigmoid_mse_bwd(const float* xrec, const float* target, const float* g_loss, const float* g_xrec, void* dh, int B,
+                         int C, int H, int W, int dtype, void* stream);
 
 /* ---- latent diffusion first stage: vector-quantisation codebook lookup ------------------------------- */
 /* Replaces VQBlock.forward (reference models/vqvaeunet.py:115-146; the same block in models/vqvae.py:13-55).

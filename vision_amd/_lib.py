@@ -134,9 +134,12 @@ SIGNATURES = {
     "vamd_nchw_to_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vamd_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vamd_adamw": (_i, [_p, _p, _p, _p, _l, _f, _p, _f, _f, _f, _f, _i, _f, _p]),
+    "vamd_adam_l2": (_i, [_p, _p, _p, _p, _l, _f, _p, _f, _f, _f, _f, _i, _f, _p]),
     "vamd_resize_ksize": (_i, [_i, _i]),
     "vamd_resize_coeffs": (_i, [_i, _i, _p, _p, _i]),
     "vamd_image_resize_u8": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _i, _i, _p, _p, _p]),
+    "vamd_sigmoid_mse_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_sigmoid_mse_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vamd_vq_workspace": (_z, [_l]),
     "vamd_vq_forward": (_i, [_p, _p, _l, _i, _i, _i, _i, _f, _p, _p, _p, _p, _z, _p]),
     "vamd_vq_backward": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p, _p]),

@@ -136,6 +136,54 @@ __global__ void l1_bwd_kernel(const T* __restrict__ pred, const float* __restric
     }
 }
 
+// Head and reconstruction loss of the VQ-VAE-UNet (reference models/vqvaeunet.py:206-210 nn.Sigmoid() after the last
+// channel-wise Linear, :236-240 F.mse_loss(x_rec, x)): h NHWC in T -> x_rec = sigmoid(h) as NCHW fp32 (what the model
+// returns) and the partial sums of (x_rec - x)^2; the backward forms g * 2 (x_rec - x) / numel * x_rec (1 - x_rec).
+template <typename T>
+__global__ void sigmoid_mse_fwd_kernel(const T* __restrict__ h, const float* __restrict__ target, float* __restrict__ xrec,
+                                       float* __restrict__ partial, int B, int C, int64_t HW) {
+    const int64_t total = (int64_t)B * HW;
+    float acc = 0.f;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / HW);
+        const int64_t hw = p - (int64_t)b * HW;
+        for (int c = 0; c < C; ++c) {
+            const float y = 1.0f / (1.0f + expf(-to_f(h[p * C + c])));
+            const int64_t o = ((int64_t)b * C + c) * HW + hw;
+            xrec[o] = y;
+            if (target) {
+                const float d = y - target[o];
+                acc = fmaf(d, d, acc);
+            }
+        }
+    }
+    if (!partial) return;
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+__global__ void sigmoid_mse_bwd_kernel(const float* __restrict__ xrec, const float* __restrict__ target,
+                                       const float* __restrict__ g_loss, const float* __restrict__ g_xrec, T* __restrict__ dh,
+                                       int B, int C, int64_t HW, float two_over_numel) {
+    const int64_t total = (int64_t)B * HW;
+    const float g = g_loss ? g_loss[0] * two_over_numel : 0.f;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(p / HW);
+        const int64_t hw = p - (int64_t)b * HW;
+        for (int c = 0; c < C; ++c) {
+            const int64_t o = ((int64_t)b * C + c) * HW + hw;
+            const float y = xrec[o];
+            float dy = target ? g * (y - target[o]) : 0.f;
+            if (g_xrec) dy += g_xrec[o];
+            dh[p * C + c] = from_f<T>(dy * y * (1.0f - y));
+        }
+    }
+}
+
 template <typename T>
 __global__ void denoise_step_kernel(float* __restrict__ cur, const T* __restrict__ eps_hat,
                                     const float* __restrict__ n, const float* __restrict__ s,
@@ -388,13 +436,16 @@ linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
     }
 }
 
+// L2 false: torch.optim.AdamW (decoupled decay p *= 1 - lr wd); true: torch.optim.Adam with weight_decay (g += wd p)
+template <bool L2>
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                              float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                              const float* __restrict__ lr_dev, float beta1, float beta2, float eps,
                              float wd, float bc1, float rsqrt_bc2, float gscale) {
     if (lr_dev) lr = lr_dev[0];
     const float step_size = lr / bc1;
-    const float decay = 1.f - lr * wd;
+    const float decay = L2 ? 1.f : 1.f - lr * wd;
+    const float l2 = L2 ? wd : 0.f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t nvec = n >> 2;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += stride) {
@@ -405,7 +456,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float gr = G[j] * gscale;
+            const float gr = L2 ? fmaf(l2, P[j], G[j] * gscale) : G[j] * gscale;
             M[j] = beta1 * M[j] + (1.f - beta1) * gr;
             V[j] = beta2 * V[j] + (1.f - beta2) * gr * gr;
             const float denom = sqrtf(V[j]) * rsqrt_bc2 + eps;
@@ -416,7 +467,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         reinterpret_cast<float4*>(v)[i] = vv;
     }
     for (int64_t i = (nvec << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float gr = g[i] * gscale;
+        const float gr = L2 ? fmaf(l2, p[i], g[i] * gscale) : g[i] * gscale;
         const float mi = beta1 * m[i] + (1.f - beta1) * gr;
         const float vi = beta2 * v[i] + (1.f - beta2) * gr * gr;
         m[i] = mi;
@@ -739,6 +790,36 @@ int vamd_l1_loss_bwd(const void* pred, const float* eps, const float* gout, void
     return 0;
 }
 
+int vamd_sigmoid_mse_fwd(const void* h, const float* target, float* xrec, float* partial, float* loss, int B, int C, int H,
+                         int W, int dtype, void* stream) {
+    VAMD_REQUIRE(h && xrec && B > 0 && C > 0 && H > 0 && W > 0, "vamd_sigmoid_mse_fwd: bad argument");
+    VAMD_REQUIRE(!target == !loss && !target == !partial, "vamd_sigmoid_mse_fwd: target, partial and loss go together");
+    const int64_t HW = (int64_t)H * W;
+    const int nchunk = vamd_l1_chunks(B * HW);
+    VAMD_DISPATCH(dtype, "vamd_sigmoid_mse_fwd", {
+        hipLaunchKernelGGL(sigmoid_mse_fwd_kernel<T>, dim3(nchunk), dim3(256), 0, as_stream(stream), (const T*)h, target, xrec,
+                           partial, B, C, HW);
+    });
+    if (target)
+        hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), partial, nchunk,
+                           1.0 / ((double)B * C * HW), loss);
+    VAMD_LAUNCH_OK("vamd_sigmoid_mse_fwd");
+    return 0;
+}
+
+int vamd_sigmoid_mse_bwd(const float* xrec, const float* target, const float* g_loss, const float* g_xrec, void* dh, int B,
+                         int C, int H, int W, int dtype, void* stream) {
+    VAMD_REQUIRE(xrec && dh && B > 0 && C > 0 && H > 0 && W > 0, "vamd_sigmoid_mse_bwd: bad argument");
+    VAMD_REQUIRE(!target == !g_loss, "vamd_sigmoid_mse_bwd: target and g_loss go together");
+    const int64_t HW = (int64_t)H * W;
+    VAMD_DISPATCH(dtype, "vamd_sigmoid_mse_bwd", {
+        hipLaunchKernelGGL(sigmoid_mse_bwd_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0, as_stream(stream), xrec, target,
+                           g_loss, g_xrec, (T*)dh, B, C, HW, (float)(2.0 / ((double)B * C * HW)));
+    });
+    VAMD_LAUNCH_OK("vamd_sigmoid_mse_bwd");
+    return 0;
+}
+
 int vamd_denoise_step(float* cur, const void* eps_hat, const float* n, const float* s,
                       const float* n_next, const float* s_next, void* next_in, float* pred_images,
                       int B, int C, int H, int W, int dtype, void* stream) {
@@ -906,19 +987,35 @@ int vamd_linear_bwd(const float* x, const float* W, const float* dy, float* dx, 
     return 0;
 }
 
+static int adam_launch(const char* what, bool l2, float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                       const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int step,
+                       float grad_scale, void* stream) {
+    VAMD_REQUIRE(p && g && m && v && n > 0 && step >= 1, "%s: bad argument", what);
+    VAMD_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
+                     ((uintptr_t)v % 16 == 0), "%s: arenas must be 16-byte aligned", what);
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    const dim3 grid(grid_for(n / 4 + 1, 256, 2048));
+    if (l2)
+        hipLaunchKernelGGL(adamw_kernel<true>, grid, dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, lr_dev, beta1, beta2,
+                           eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, grid, dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, lr_dev, beta1, beta2,
+                           eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+    VAMD_LAUNCH_OK(what);
+    return 0;
+}
+
 int vamd_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                int step, float grad_scale, void* stream) {
-    VAMD_REQUIRE(p && g && m && v && n > 0 && step >= 1, "vamd_adamw: bad argument");
-    VAMD_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
-                     ((uintptr_t)v % 16 == 0), "vamd_adamw: arenas must be 16-byte aligned");
-    const double bc1 = 1.0 - pow((double)beta1, step);
-    const double bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0,
-                       as_stream(stream), p, g, m, v, n, lr, lr_dev, beta1, beta2, eps, weight_decay,
-                       (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
-    VAMD_LAUNCH_OK("vamd_adamw");
-    return 0;
+    return adam_launch("vamd_adamw", false, p, g, m, v, n, lr, lr_dev, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
+}
+
+int vamd_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                 const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                 int step, float grad_scale, void* stream) {
+    return adam_launch("vamd_adam_l2", true, p, g, m, v, n, lr, lr_dev, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
 }
 
 int vamd_repack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int ksize, int dtype,

@@ -338,10 +338,12 @@ class _ResBlock:
         self.eng, self.spec = eng, spec
         self.bn1 = _Norm(eng, p + ".block1.0.0", spec.cin, True)
         self.conv1 = _Conv(eng, p + ".block1.0.2", spec.cin, spec.cout, 3)
-        self.temb = _Linear(eng, p + ".linear_temb", tf, spec.cout, act_in=True)
+        self.temb = _Linear(eng, p + ".linear_temb", tf, spec.cout, act_in=True) if tf else None   # no time embedding: tf = 0
         self.bn2 = _Norm(eng, p + ".block2.0.0", spec.cout, True)
         self.conv2 = _Conv(eng, p + ".block2.0.3", spec.cout, spec.cout, 3)
-        self.short = _Conv(eng, p + ".layers.0", spec.cin, spec.cout, 1) if spec.cin != spec.cout else None
+        # the 1x1 shortcut: an nn.Conv2d (DDPM) or a channel-wise nn.Linear wrapped in a module (the VQ-VAE-UNet blocks);
+        # both store [Cout][Cin] row-major
+        self.short = _Conv(eng, p + getattr(eng, "shortcut_key", ".layers.0"), spec.cin, spec.cout, 1) if spec.cin != spec.cout else None
         self.convs = [c for c in (self.conv1, self.conv2, self.short) if c is not None]
         self._gb_stale = False                   # conv1's bias gradient holds an eval-mode value
         # nn.Dropout's 1/(1-p) stays an fp32 kernel argument; the mask tensor holds exact 0/1 values
@@ -363,8 +365,8 @@ class _ResBlock:
         if a1 is None:
             a1, coef1 = self.bn1.fwd(x, training)
         # projected with the other blocks' in one launch, if this is the embedding that launch projected
-        tproj = self.eng.tproj_for.get(id(self)) if self.eng.tproj_src is temb else None
-        if tproj is None:
+        tproj = self.eng.tproj_for.get(id(self)) if (self.temb is not None and self.eng.tproj_src is temb) else None
+        if tproj is None and self.temb is not None:
             tproj = self.temb.fwd(temb)
         if fuse:
             sc = self.short.fwd(x) if self.short is not None else x
@@ -406,10 +408,13 @@ class _ResBlock:
             dxs = self.short.dgrad(dy, x.shape) if need_dx else None
         # d(projected temb)[b][c] = sum over pixels of dh1; conv1 bias gradient = its sum over b: both
         # come out of the BatchNorm backward's statistics pass (dh1 is affine in the summed terms)
-        dtproj = torch.empty((dy.shape[0], self.spec.cout), dtype=torch.float32, device=dy.device)
-        dh1 = self.bn2.bwd(da2, h1, coef2, mask, img_sums=(dtproj, self.conv1.gb), training=training,
-                           mask_scale=self.mask_scale)
-        self.temb.bwd(temb, dtproj, dx=dtemb, accumulate=True)
+        if self.temb is not None:
+            dtproj = torch.empty((dy.shape[0], self.spec.cout), dtype=torch.float32, device=dy.device)
+            dh1 = self.bn2.bwd(da2, h1, coef2, mask, img_sums=(dtproj, self.conv1.gb), training=training,
+                               mask_scale=self.mask_scale)
+            self.temb.bwd(temb, dtproj, dx=dtemb, accumulate=True)
+        else:
+            dh1 = self.bn2.bwd(da2, h1, coef2, mask, training=training, mask_scale=self.mask_scale)
         # conv1's bias feeds a train-mode BatchNorm, whose mean subtraction cancels it: the
         # gradient is exactly zero (dh1 sums to zero over the batch) and is not computed
         if training and self._gb_stale:
@@ -568,6 +573,11 @@ class _Resample:
 
 class Engine:
     def __init__(self, module: torch.nn.Module, plan: UNetPlan, dtype: torch.dtype, algo=_lib.ALGO_AUTO):
+        self._init_arenas(module, plan, dtype, algo)
+        self._init_layers(plan)
+
+    def _init_arenas(self, module, plan, dtype, algo):
+        """Parameters, gradients and BatchNorm buffers of `module` become views of flat arenas; launch-independent state."""
         params = list(module.named_parameters())
         if not params or params[0][1].device.type != "cuda":
             raise RuntimeError("vision_amd needs its parameters on a HIP device (cuda:N); there is no CPU path")
@@ -622,7 +632,15 @@ class Engine:
         self._params = [p for _, p in params]
         self.reducer = None               # set by vision_amd.parallel.DataParallel
         self._versions = None
+        self.coef_epoch = 0
+        self.dirty = True
+        self._repack_table = None
+        self.drop_generator = None
+        self.profile = None               # list -> receives (kind, flops, start, end) per MFMA conv launch
+        self.debug_taps = None            # dict -> receives (output, folded skip) per layer (diagnostics)
+        self._tproj_cache, self.tproj_for, self.tproj_src = {}, {}, None
 
+    def _init_layers(self, plan):
         tf = plan.time_features
         self.lin1 = _Linear(self, "linear_1", plan.ch, tf, act_in=False)
         self.lin2 = _Linear(self, "linear_2", tf, tf, act_in=True)
@@ -641,15 +659,8 @@ class Engine:
         # (models/ddpm.py:126-134) on the host, once
         freqs = torch.exp(torch.linspace(math.log(1.0), math.log(1000.0), plan.ch // 2))
         self.angular = (2.0 * math.pi * freqs).to(self.device)
-        self.coef_epoch = 0
-        self._tproj_cache, self.tproj_for, self.tproj_src = {}, {}, None
         self._lows = {spec.prefix: self._layer_low(spec.prefix) for spec in plan.layers}
         self._lows["End"] = self._layer_low("End")
-        self.dirty = True
-        self._repack_table = None
-        self.drop_generator = None
-        self.profile = None               # list -> receives (kind, flops, start, end) per MFMA conv launch
-        self.debug_taps = None            # dict -> receives (output, folded skip) per layer (diagnostics)
 
     def _rebind_buffer(self, module, name, view):
         owner, _, leaf = name.rpartition(".")

@@ -91,3 +91,57 @@ def make_plan(config) -> UNetPlan:
             pos += 1
     return UNetPlan(layers=layers, ch=dims[1], time_features=4 * dims[1], end_channels=width,
                     patch_size=int(config["patch_size"]), with_conv=bool(config["with_conv"]))
+
+
+VQ_REQUIRED_KEYS = ("h_dims", "patch_size", "num_embed", "embed_dim", "sampling_period", "attn_res", "down_index")
+
+
+def make_vq_plan(config) -> UNetPlan:
+    """Layer plan of the VQ-VAE-UNet first stage (reference models/vqvaeunet.py:150-203): per level a ResNetBlock and,
+    where down_index says so, a DownBlock; mirrored by UpBlock + ResNetBlock per level; the codebook lookup sits between
+    the two halves, the channel-wise Linear + Sigmoid head after them.  The blocks take no time embedding
+    (time_features = 0) and always resample with convolutions (models/vqvaeunet.py:161)."""
+    for k in VQ_REQUIRED_KEYS:
+        if k not in config:
+            raise KeyError(k)          # the reference indexes config[...] directly (models/vqvaeunet.py:153-159)
+    dims = list(config["h_dims"])
+    down_flags = list(config["down_index"])
+    attn_at = list(config["attn_res"])
+    levels = len(dims) - 1
+    layers: List[LayerSpec] = []
+
+    def no_attention(res):
+        # the reference's test is `f_res in attn_res` on a value that is a float after the first halving
+        if res in attn_at:
+            raise NotImplementedError(
+                f"attn_res {attn_at} puts an AttnBlock at resolution {res}: the first stage's channel-attention block "
+                "(models/vqvaeunet.py:83-100) is not built; neither shipped configuration instantiates it")
+
+    res = config["patch_size"]
+    pos = 0
+    width = dims[0]
+    for lvl in range(levels):
+        width_in, width = dims[lvl], dims[lvl + 1]
+        layers.append(LayerSpec("Downsampling", pos, "res", width_in, width, int(res), int(res)))
+        pos += 1
+        no_attention(res)                                        # checked before the level's DownBlock
+        if down_flags[lvl + 1] == 1:
+            layers.append(LayerSpec("Downsampling", pos, "down", width, width, int(res), (int(res) - 1) // 2 + 1))
+            pos += 1
+            res = res / 2
+    if width != int(config["embed_dim"]):
+        raise ValueError(f"embed_dim {config['embed_dim']} must equal the encoder's last width {width}: the codebook "
+                         "rows replace the encoder's output vectors (models/vqvaeunet.py:118,210)")
+    rdims, rflags = dims[::-1], down_flags[::-1]
+    pos = 0
+    for lvl in range(levels):
+        width_in, width = rdims[lvl], rdims[lvl + 1]
+        if rflags[lvl] == 1:
+            layers.append(LayerSpec("Upsampling", pos, "up", width_in, width_in, int(res), int(res) * 2))
+            pos += 1
+            res = res * 2
+        layers.append(LayerSpec("Upsampling", pos, "res", width_in, width, int(res), int(res)))
+        pos += 1
+        no_attention(res)                                        # checked after the level's UpBlock
+    return UNetPlan(layers=layers, ch=0, time_features=0, end_channels=width,
+                    patch_size=int(config["patch_size"]), with_conv=True)

@@ -242,6 +242,7 @@ class Trainer:
         device = self._attach(model)
         datamodule.device = device
         datamodule.setup()
+        self.datamodule = datamodule                  # models read trainer.datamodule (reference models/vqvaeunet.py:294)
         cfg = model.configure_optimizers()
         if cfg is None:
             # the reference returns None when scheduler_gamma is present but null (models/ddpm.py:347-352),
@@ -272,7 +273,8 @@ class Trainer:
             for s in scheds:
                 s.step()
             train_metrics = self._flush(["TL"])
-            model.on_train_epoch_end()
+            if hasattr(model, "on_train_epoch_end"):
+                model.on_train_epoch_end()
             model.eval()
             with torch.no_grad():
                 for i, batch in enumerate(datamodule.val_dataloader()):
@@ -284,7 +286,9 @@ class Trainer:
             if self.logger is not None and self.is_global_zero:
                 self.logger.log_metrics({**self.callback_metrics, "lr": opt.param_groups[0]["lr"]}, self.global_step)
             with torch.no_grad():
-                model.on_validation_end()
+                for hook in ("on_validation_epoch_end", "on_validation_end"):      # Lightning's order
+                    if hasattr(model, hook):
+                        getattr(model, hook)()
                 if self.is_global_zero:
                     for cb in self.callbacks:
                         if hasattr(cb, "on_validation_end"):
