@@ -82,11 +82,10 @@ def load_reference_ddpm():
     return mod
 
 
-def load_reference_vqblock():
-    """The reference module models/vqvaeunet.py (its `VQBlock`, models/vqvaeunet.py:104-146).  The file does
-    `from . import Custumnn` (models/vqvaeunet.py:10), so it is executed as a submodule of an empty stand-in
-    package whose search path is the reference's models/ directory -- models/__init__.py itself (which imports
-    every model family) is not run."""
+def _load_models_file(stem):
+    """Execute reference models/<stem>.py as a submodule of an empty stand-in package whose search path is the
+    reference's models/ directory (the files do `from . import Custumnn`); models/__init__.py itself, which imports
+    every model family, is not run."""
     if not reference_available():
         raise FileNotFoundError(f"reference not mounted at {REFERENCE_ROOT}")
     _install_stubs()
@@ -95,8 +94,18 @@ def load_reference_vqblock():
         pkg = types.ModuleType("ref_models")
         pkg.__path__ = [pkg_dir]
         sys.modules["ref_models"] = pkg
-    spec = importlib.util.spec_from_file_location("ref_models.vqvaeunet", os.path.join(pkg_dir, "vqvaeunet.py"))
+    spec = importlib.util.spec_from_file_location(f"ref_models.{stem}", os.path.join(pkg_dir, f"{stem}.py"))
     mod = importlib.util.module_from_spec(spec)
-    sys.modules["ref_models.vqvaeunet"] = mod
+    sys.modules[f"ref_models.{stem}"] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_reference_vqblock():
+    """The reference module models/vqvaeunet.py (its `VQBlock`, models/vqvaeunet.py:104-146, and `VQVAEUNETModel`)."""
+    return _load_models_file("vqvaeunet")
+
+
+def load_reference_ldm():
+    """The reference module models/ldm.py (its blocks and `LatentDiffusion`)."""
+    return _load_models_file("ldm")

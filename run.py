@@ -64,6 +64,18 @@ def main(argv=None):
         except Exception as e:  # the reference swallows resume errors too (run.py:58)
             print(f"Error loading checkpoint: {e}")
 
+    # latent diffusion: `first_stage_config` names the YAML of the autoencoder whose latents are diffused and
+    # `first_stage_checkpoint` (optional) its trained weights; without a checkpoint the first stage keeps its seeded
+    # initialisation (smoke runs).  The reference has no entry for models/ldm.py at all.
+    fs_yaml = config["model_config"].get("first_stage_config")
+    if fs_yaml is not None:
+        with open(fs_yaml, "r") as f:
+            fs_cfg = yaml.safe_load(f)["model_config"]
+        fs_ckpt = config["model_config"].get("first_stage_checkpoint")
+        fs_cls = get_model(fs_cfg["name"], fs_cfg).__class__
+        first = fs_cls.load_from_checkpoint(fs_ckpt, config=fs_cfg) if fs_ckpt else get_model(fs_cfg["name"], fs_cfg)
+        model.set_first_stage(first)
+
     checkpoint = SafetensorsCheckpoint(config_path=args.filename, dirpath=os.path.join(logger.log_dir, "checkpoints"),
                                        monitor="VL", mode="min", save_top_k=2, save_last=True,
                                        filename="epoch={epoch}-VL={VL:.2f}")

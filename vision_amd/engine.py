@@ -235,14 +235,16 @@ FUSE_ATTENTION = os.environ.get("VAMD_ATTN_FUSE", "0") != "0"
 class _Norm:
     """Statistics + fused scale/shift/LeakyReLU(/dropout) of BatchNorm2d (G = 1) or GroupNorm (G = B)."""
 
-    def __init__(self, eng, name, C_, batchnorm: bool):
+    def __init__(self, eng, name, C_, batchnorm: bool, slope=None):
         self.eng, self.C, self.bn = eng, C_, batchnorm
         self.gamma, self.beta = eng.param(name + ".weight"), eng.param(name + ".bias")
         self.ggamma, self.gbeta = eng.grad(name + ".weight"), eng.grad(name + ".bias")
         if batchnorm:
             self.rm, self.rv = eng.buffer(name + ".running_mean"), eng.buffer(name + ".running_var")
             self.nbt = eng.buffer(name + ".num_batches_tracked")
-        self.slope = LEAKY_SLOPE if batchnorm else 1.0
+        # the activation that follows the norm in the reference: LeakyReLU after a block's BatchNorm, none (slope 1)
+        # after an attention block's norm
+        self.slope = slope if slope is not None else (LEAKY_SLOPE if batchnorm else 1.0)
         self._eval_coef, self._eval_key = None, None
 
     def eval_coef(self):
@@ -338,12 +340,12 @@ class _ResBlock:
         self.eng, self.spec = eng, spec
         self.bn1 = _Norm(eng, p + ".block1.0.0", spec.cin, True)
         self.conv1 = _Conv(eng, p + ".block1.0.2", spec.cin, spec.cout, 3)
-        self.temb = _Linear(eng, p + ".linear_temb", tf, spec.cout, act_in=True) if tf else None   # no time embedding: tf = 0
+        self.temb = _Linear(eng, p + ".linear_temb" + eng.linear_suffix, tf, spec.cout, act_in=True) if tf else None   # no time embedding: tf = 0
         self.bn2 = _Norm(eng, p + ".block2.0.0", spec.cout, True)
         self.conv2 = _Conv(eng, p + ".block2.0.3", spec.cout, spec.cout, 3)
         # the 1x1 shortcut: an nn.Conv2d (DDPM) or a channel-wise nn.Linear wrapped in a module (the VQ-VAE-UNet blocks);
         # both store [Cout][Cin] row-major
-        self.short = _Conv(eng, p + getattr(eng, "shortcut_key", ".layers.0"), spec.cin, spec.cout, 1) if spec.cin != spec.cout else None
+        self.short = _Conv(eng, p + eng.shortcut_key, spec.cin, spec.cout, 1) if spec.cin != spec.cout else None
         self.convs = [c for c in (self.conv1, self.conv2, self.short) if c is not None]
         self._gb_stale = False                   # conv1's bias gradient holds an eval-mode value
         # nn.Dropout's 1/(1-p) stays an fp32 kernel argument; the mask tensor holds exact 0/1 values
@@ -516,6 +518,68 @@ class _AttnBlock:
         return self.norm.bwd(dhn, x, coef, None, add=dy, add2=extra, need_dx=need_dx)
 
 
+class _ChanAttnBlock(_AttnBlock):
+    """The attention block of the reference's latent-diffusion and first-stage files (models/ldm.py:91-108,
+    models/vqvaeunet.py:83-100): BatchNorm2d without an activation, ONE channel-wise Linear whose output serves as
+    query, key and value, attention BETWEEN CHANNELS (scores [B, C, C] = p p^T * C^-0.5 over the H*W positions, softmax
+    over the second channel axis), a second Linear, residual.  With p stored [B][S][C]:
+        scores = pT pT^T (pT = p transposed, rows padded to 8), W = softmax(scores), o = p W^T, y = x + linear2(o)."""
+
+    def __init__(self, eng, spec: LayerSpec):
+        p = spec.prefix
+        self.eng, self.spec, self.C = eng, spec, spec.cout
+        self.norm = _Norm(eng, p + ".norm", self.C, True, slope=1.0)
+        self.lin1 = _Conv(eng, p + ".linear1.linear", self.C, self.C, 1)
+        self.lin2 = _Conv(eng, p + ".linear2.linear", self.C, self.C, 1)
+        self.convs = [self.lin1, self.lin2]
+
+    def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False, next_norm=None):
+        B, H, W, Cc = x.shape
+        S = H * W
+        Sp = (S + 7) // 8 * 8
+        e, dev = self.eng, x.device
+        hn, coef = self.norm.fwd(x, training)
+        p = self.lin1.fwd(hn)
+        pT = self._transpose_padded(p, B, S, Cc, Sp)                          # [B][C][Sp]
+        scores = torch.empty((B, Cc, Cc), dtype=torch.float32, device=dev)
+        self._bmm_nt(pT, pT, scores, B, Cc, Cc, S, Sp, Sp, Cc, Cc ** -0.5)
+        Wt = torch.empty((B, Cc, Cc), dtype=e.dtype, device=dev)
+        call("vamd_softmax_rows", _ptr(scores), _ptr(Wt), B * Cc, Cc, Cc, e.dt, _stream())
+        o = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)             # o[s][c1] = sum_c2 W[c1][c2] p[s][c2]
+        self._bmm_nt(p, Wt, o, B, S, Cc, Cc, Cc, Cc, Cc, 1.0)
+        got = self.lin2.fwd_act(o, next_norm, res=x, res2=res2, want_raw=True) if next_norm is not None else None
+        if got is not None:
+            e.act_for[got[1].data_ptr()] = got[0]
+            return got[1]
+        y = self.lin2.fwd(o, res=x, res2=res2, want_stats=want_stats)
+        if tape is not None:
+            tape.append((self, (x, hn, coef, p, pT, Wt, o, training)))
+        return y
+
+    def bwd(self, saved, dy, extra, dtemb, need_dx=True):
+        x, hn, coef, p, pT, Wt, o, training = saved
+        e, dev = self.eng, x.device
+        B, H, W, Cc = x.shape
+        S = H * W
+        Sp = pT.shape[2]
+        self.lin2.wgrad(dy, o)
+        do = self.lin2.dgrad(dy, o.shape)
+        doT = self._transpose_padded(do, B, S, Cc, Sp)
+        dW = torch.empty((B, Cc, Cc), dtype=torch.float32, device=dev)        # dW[c1][c2] = sum_s do[s][c1] p[s][c2]
+        self._bmm_nt(doT, pT, dW, B, Cc, Cc, S, Sp, Sp, Cc, 1.0)
+        dS = torch.empty((B, Cc, Cc), dtype=e.dtype, device=dev)
+        call("vamd_softmax_rows_bwd", _ptr(Wt), _ptr(dW), _ptr(dS), B * Cc, Cc, Cc, Cc ** -0.5, e.dt, _stream())
+        # dp[s][c] = sum_c1 do[s][c1] W[c1][c] + sum_c2 dS[c][c2] p[s][c2] + sum_c1 dS[c1][c] p[s][c1]: one product
+        # [do | p | p] x [W^T | dS | dS^T]^T over 3C, so the three terms meet in the fp32 accumulators
+        lhs = torch.cat([do.view(B, S, Cc), p.view(B, S, Cc), p.view(B, S, Cc)], dim=2)
+        rhs = torch.cat([self._transpose_padded(Wt, B, Cc, Cc, Cc), dS, self._transpose_padded(dS, B, Cc, Cc, Cc)], dim=2)
+        dp = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)
+        self._bmm_nt(lhs, rhs, dp, B, S, Cc, 3 * Cc, 3 * Cc, 3 * Cc, Cc, 1.0)
+        self.lin1.wgrad(dp, hn)
+        dhn = self.lin1.dgrad(dp, hn.shape)
+        return self.norm.bwd(dhn, x, coef, None, add=dy, add2=extra, need_dx=need_dx, training=training)
+
+
 class _Resample:
     """DownBlock (conv 3x3 stride 2, or AvgPool2d((2, 2)) when the model is built with with_conv false) /
     UpBlock (nearest 2x upsample, fused into the conv 3x3 that follows it when there is one);
@@ -572,6 +636,11 @@ class _Resample:
 
 
 class Engine:
+    # parameter-key conventions of the reference file the model comes from (models/ddpm.py: 1x1 nn.Conv2d everywhere)
+    shortcut_key = ".layers.0"           # a block's 1x1 shortcut
+    linear_suffix = ""                   # time-embedding linears, their per-block projections and the End projection
+    attn_block = _AttnBlock
+
     def __init__(self, module: torch.nn.Module, plan: UNetPlan, dtype: torch.dtype, algo=_lib.ALGO_AUTO):
         self._init_arenas(module, plan, dtype, algo)
         self._init_layers(plan)
@@ -642,17 +711,17 @@ class Engine:
 
     def _init_layers(self, plan):
         tf = plan.time_features
-        self.lin1 = _Linear(self, "linear_1", plan.ch, tf, act_in=False)
-        self.lin2 = _Linear(self, "linear_2", tf, tf, act_in=True)
+        self.lin1 = _Linear(self, "linear_1" + self.linear_suffix, plan.ch, tf, act_in=False)
+        self.lin2 = _Linear(self, "linear_2" + self.linear_suffix, tf, tf, act_in=True)
         self.layers = []
         for spec in plan.layers:
             if spec.kind == "res":
                 self.layers.append(_ResBlock(self, spec, tf))
             elif spec.kind == "attn":
-                self.layers.append(_AttnBlock(self, spec))
+                self.layers.append(self.attn_block(self, spec))
             else:
                 self.layers.append(_Resample(self, spec))
-        self.end = _Conv(self, "End.0.0", plan.end_channels, plan.end_channels, 1)
+        self.end = _Conv(self, "End.0.0" + self.linear_suffix, plan.end_channels, plan.end_channels, 1)
         self.n_down = len(plan.section("Downsampling"))
         self.n_mid = len(plan.section("Middle"))
         # 2*pi*exp(linspace(ln 1, ln 1000, ch/2)) tabulated with the reference's own op sequence
@@ -858,3 +927,11 @@ class Engine:
         for (name, g), p in zip(self._g.items(), self._params):
             if p.grad is not g:
                 p.grad = g
+
+
+class LatentEngine(Engine):
+    """The latent-space UNet of reference models/ldm.py: the DDPM graph with channel-wise nn.Linear modules (wrapped, key
+    `.linear`) where models/ddpm.py has 1x1 convolutions, and the channel-attention block."""
+    shortcut_key = ".layers.0.linear"
+    linear_suffix = ".linear"
+    attn_block = _ChanAttnBlock

@@ -1,0 +1,208 @@
+"""MI355X-native `LatentDiffusion`: the DDPM training step and sampler over the latents of the VQ-VAE-UNet first stage,
+with the surface of the reference's models/ldm.py (constructor keys, attributes, method names, state_dict keys).
+
+The reference class cannot be constructed as shipped -- its constructor reads `self.attn_resolutions`, which it never
+sets (models/ldm.py:179, :206; it sets `self.attn_res`, :149), `generate` reads `self.patch_size` (:297) and the
+schedule reads `self.curr_device` (:250), set only inside the step methods -- it is registered nowhere
+(models/__init__.py:13-26) and no YAML exists for it.  What IS pinned by the reference is the network and the
+objective: with the missing attribute supplied from outside, the reference's own `forward` and `p_loss` run unmodified
+(oracle/make_golden_ldm.py), and the tests compare this class with those outputs.  This build's own definitions, where
+the reference has none:
+
+* `attn_resolutions` = `attn_res`; `patch_size` = `in_res`; the network's input has `h_dims[0]` channels at
+  `in_res` x `in_res` (the latents: 256 x 7 x 7 for configs/butterfly_vqvaeunet.yaml);
+* `encoder` / `decoder` config entries are stored and unused, as in the reference (models/ldm.py:156-157);
+* a first stage is attached with `set_first_stage(model)`: the step methods then take image batches and diffuse the
+  first stage's encoder output (eval mode, no gradient, before quantisation); without one they take latents;
+* `decode_latents(latents, skip=None)`: codebook lookup, then the first stage's decoder.  That decoder consumes the
+  encoder's skips (models/vqvaeunet.py:224-233), so decoding a SAMPLED latent is undefined in the reference: here
+  absent skips are zeros.
+"""
+import os
+
+import torch
+from torch import nn
+
+from . import _lib
+from .ddpm import _DTYPES, DDPMModel, _DownParams, _UpParams, _conv
+from .engine import LatentEngine
+from .lightning_shim import LightningModule
+from .plan import make_ldm_plan
+from .utils import save_image_grid
+from .vqvaeunet import _ChannelLinear
+
+
+class _ResParams(nn.Module):
+    """Key layout and creation order of the reference block (models/ldm.py:44-70)."""
+
+    def __init__(self, cin, cout, act, time_features, dropout=0.0):
+        super().__init__()
+        self.act = act
+        self.linear_temb = _ChannelLinear(time_features, cout)
+        self.block1 = nn.ModuleList([nn.Sequential(nn.BatchNorm2d(cin), act, _conv(cin, cout, 3, padding=1))])
+        self.block2 = nn.ModuleList([nn.Sequential(nn.BatchNorm2d(cout), act, nn.Dropout(dropout),
+                                                   _conv(cout, cout, 3, padding=1))])
+        self.layers = nn.ModuleList([_ChannelLinear(cin, cout)]) if cin != cout else None
+
+
+class _AttnParams(nn.Module):
+    """reference models/ldm.py:91-96."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.linear1 = _ChannelLinear(c, c)
+        self.linear2 = _ChannelLinear(c, c)
+        self.norm = nn.BatchNorm2d(c)
+
+
+class LatentDiffusion(DDPMModel):
+    def __init__(self, config, **kwargs):
+        LightningModule.__init__(self)
+        self.config = config
+        plan = make_ldm_plan(config)
+        self._plan = plan
+        self.h_dims = config.get("h_dims")
+        self.in_res = config.get("in_res")
+        self.attn_res = config.get("attn_res")
+        self.attn_resolutions = self.attn_res
+        self.down_index = config.get("down_index")
+        self.with_conv = config.get("with_conv")
+        self.dropout = config.get("dropout")
+        self.diffusion_steps = config.get("diffusion_steps")
+        self.sampling_period = config.get("sampling_period")
+        self.grid = config.get("grid")
+        self.encoder = config.get("encoder")
+        self.decoder = config.get("decoder")
+        self.patch_size = self.in_res
+        self.act = nn.LeakyReLU()
+        self.num_channels = len(self.h_dims)
+        self.ch = self.h_dims[1]
+        dt = kwargs.get("compute_dtype", config.get("compute_dtype", "bf16"))
+        self.compute_dtype = dt if isinstance(dt, torch.dtype) else _DTYPES[dt]
+        self.kernel_algo = int(kwargs.get("kernel_algo", config.get("kernel_algo", _lib.ALGO_AUTO)))
+
+        # creation order = RNG order of the default initialisers (reference models/ldm.py:163-221)
+        self.linear_1 = _ChannelLinear(self.ch, self.ch * 4)
+        self.linear_2 = _ChannelLinear(self.ch * 4, self.ch * 4)
+        self.time_features = self.ch * 4
+        sections = {"Downsampling": nn.ModuleList(), "Middle": nn.ModuleList(), "Upsampling": nn.ModuleList()}
+        for spec in plan.layers:
+            if spec.kind == "res":
+                m = _ResParams(spec.cin, spec.cout, self.act, self.time_features, spec.dropout)
+            elif spec.kind == "attn":
+                m = _AttnParams(spec.cout)
+            elif spec.kind == "down":
+                m = _DownParams(spec.cout, self.with_conv)
+            else:
+                m = _UpParams(spec.cin, self.with_conv)
+            sections[spec.section].append(m)
+        self.Downsampling = sections["Downsampling"]
+        self.Middle = sections["Middle"]
+        self.reversed_h_dims = self.h_dims[::-1]
+        self.reversed_down_index = self.down_index[::-1]
+        self.Upsampling = sections["Upsampling"]
+        self.End = nn.ModuleList([nn.Sequential(_ChannelLinear(plan.end_channels, plan.end_channels))])
+        self.train_losses = []
+        self.val_losses = []
+        self._engine = None
+        self._drop_masks = None
+        self._last_pred_nhwc = None
+        self.grad_reducer = None
+        self.curr_device = None
+        object.__setattr__(self, "_first_stage", None)       # not a submodule: its weights are not this model's
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _ensure_engine(self) -> LatentEngine:
+        eng = self._engine
+        if eng is None or not eng.owns(self) or eng.dtype != self.compute_dtype:
+            eng = LatentEngine(self, self._plan, self.compute_dtype, self.kernel_algo)
+            object.__setattr__(self, "_engine", eng)
+        return eng
+
+    def _anchor(self):
+        w = self.linear_1.linear.weight
+        return w if torch.is_grad_enabled() else w.detach()
+
+    # ------------------------------------------------------------------ first stage
+    def set_first_stage(self, model):
+        """Attach a trained `VQVAEUNETModel`; its parameters stay its own (not saved with, nor trained by, this model)."""
+        if model is not None and model.embed_dim != self.h_dims[0]:
+            raise ValueError(f"the first stage's latents have {model.embed_dim} channels, this network takes {self.h_dims[0]}")
+        object.__setattr__(self, "_first_stage", model)
+        return self
+
+    @property
+    def first_stage(self):
+        return self._first_stage
+
+    def _stage_on(self, device):
+        fs = self._first_stage
+        if fs is None:
+            raise RuntimeError("no first stage attached (set_first_stage)")
+        if next(fs.parameters()).device != device:       # it is not a submodule, so .to() of this model does not move it
+            fs.to(device)
+        return fs
+
+    @torch.no_grad()
+    def encode_images(self, x):
+        """Images -> the first stage's encoder output (before quantisation), NCHW fp32."""
+        fs = self._stage_on(x.device)
+        was = fs.training
+        fs.eval()
+        try:
+            z, _ = fs.encode(x)
+        finally:
+            fs.train(was)
+        return z
+
+    @torch.no_grad()
+    def decode_latents(self, latents, skip=None):
+        """Codebook lookup (codes in `self.last_codes`), then the first stage's decoder; absent skips are zeros."""
+        fs = self._stage_on(latents.device)
+        was = fs.training
+        fs.eval()
+        try:
+            q, _, codes = fs.quantize(latents)
+            self.last_codes = codes
+            if skip is None:
+                B = latents.shape[0]
+                dev = latents.device
+                skip = [torch.zeros((B, s.cout, s.res_out, s.res_out), device=dev) for s in fs._plan.section("Downsampling")]
+            return fs.decode(q, skip)
+        finally:
+            fs.train(was)
+
+    def _latents_of(self, batch):
+        x_0, _ = batch
+        self.curr_device = x_0.device
+        if self._first_stage is not None and x_0.shape[1] != self.h_dims[0]:
+            return self.encode_images(x_0)
+        return x_0
+
+    # ------------------------------------------------------------------ reference surface (models/ldm.py:290-360)
+    def generate(self, num_images, diffusion_steps, initial_noise=None):
+        if initial_noise is None:
+            initial_noise = torch.randn((num_images, self.h_dims[0], self.in_res, self.in_res), device=self._anchor().device)
+        return self.reverse_diffusion(initial_noise, diffusion_steps)
+
+    def training_step(self, batch, batch_idx):
+        return super().training_step((self._latents_of(batch), None), batch_idx)
+
+    def validation_step(self, batch, batch_idx):
+        return super().validation_step((self._latents_of(batch), None), batch_idx)
+
+    def test_step(self, batch, batch_idx):
+        return super().test_step((self._latents_of(batch), None), batch_idx)
+
+    def sample_images(self):
+        """Sampled latents, decoded through the first stage when one is attached (reference models/ldm.py:362-373 saves
+        the sampler's output as an image; latents of 256 channels are not one)."""
+        latents = self.generate(self.grid ** 2, self.diffusion_steps)
+        if self._first_stage is None:
+            return latents
+        images = self.decode_latents(latents)
+        samples_dir = os.path.join(self.logger.log_dir, "Samples")
+        os.makedirs(samples_dir, exist_ok=True)
+        save_image_grid(images.cpu(), os.path.join(samples_dir, f"{self.logger.name}_Epoch_{self.current_epoch}.png"),
+                        normalize=True, nrow=self.grid)
+        return images

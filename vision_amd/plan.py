@@ -41,19 +41,14 @@ class UNetPlan:
         return [l for l in self.layers if l.section == name]
 
 
-def make_plan(config) -> UNetPlan:
-    for k in REQUIRED_KEYS:
-        if k not in config:
-            raise KeyError(k)          # the reference indexes config[...] directly (models/ddpm.py:142-153)
-    dims = list(config["h_dims"])
-    down_flags = list(config["down_index"])
-    attn_at = list(config["attn_res"])
+def _unet_plan(dims, down_flags, attn_at, res, with_conv, p, patch_size) -> UNetPlan:
+    """Module sequence of the time-conditioned UNet (reference models/ddpm.py:160-204; models/ldm.py:170-214 builds the
+    same sequence)."""
     levels = len(dims) - 1
     layers: List[LayerSpec] = []
 
     # The reference tracks the feature resolution in a variable that becomes a float after the
     # first halving and tests `f_res in attn_res`; int/float equality makes 112.0 match 112.
-    res = config["patch_size"]
     pos = 0
     width = dims[0]
     for lvl in range(levels):
@@ -65,12 +60,11 @@ def make_plan(config) -> UNetPlan:
             pos += 1
         if down_flags[lvl + 1] == 1:
             # conv 3x3 stride 2 pad 1 (== res/2 for even res); AvgPool2d((2, 2)) floors
-            half = (int(res) - 1) // 2 + 1 if bool(config["with_conv"]) else int(res) // 2
+            half = (int(res) - 1) // 2 + 1 if with_conv else int(res) // 2
             layers.append(LayerSpec("Downsampling", pos, "down", width, width, int(res), half))
             pos += 1
             res = res / 2
 
-    p = float(config["dropout"])
     r = int(res)
     layers.append(LayerSpec("Middle", 0, "res", width, width, r, r, p))
     layers.append(LayerSpec("Middle", 1, "attn", width, width, r, r))
@@ -90,7 +84,30 @@ def make_plan(config) -> UNetPlan:
             layers.append(LayerSpec("Upsampling", pos, "attn", width, width, int(res), int(res)))
             pos += 1
     return UNetPlan(layers=layers, ch=dims[1], time_features=4 * dims[1], end_channels=width,
-                    patch_size=int(config["patch_size"]), with_conv=bool(config["with_conv"]))
+                    patch_size=int(patch_size), with_conv=with_conv)
+
+
+def make_plan(config) -> UNetPlan:
+    for k in REQUIRED_KEYS:
+        if k not in config:
+            raise KeyError(k)          # the reference indexes config[...] directly (models/ddpm.py:142-153)
+    return _unet_plan(list(config["h_dims"]), list(config["down_index"]), list(config["attn_res"]), config["patch_size"],
+                      bool(config["with_conv"]), float(config["dropout"]), config["patch_size"])
+
+
+LDM_REQUIRED_KEYS = ("h_dims", "in_res", "attn_res", "down_index", "with_conv", "dropout", "diffusion_steps",
+                     "sampling_period", "grid")
+
+
+def make_ldm_plan(config) -> UNetPlan:
+    """The latent-space UNet (reference models/ldm.py:139-221): the DDPM module sequence over `in_res` x `in_res` maps
+    of h_dims[0] channels.  The reference reads these keys with config.get and fails later on a None; a missing key is
+    reported here."""
+    for k in LDM_REQUIRED_KEYS:
+        if config.get(k) is None:
+            raise KeyError(k)
+    return _unet_plan(list(config["h_dims"]), list(config["down_index"]), list(config["attn_res"]), config["in_res"],
+                      bool(config["with_conv"]), float(config["dropout"]), config["in_res"])
 
 
 VQ_REQUIRED_KEYS = ("h_dims", "patch_size", "num_embed", "embed_dim", "sampling_period", "attn_res", "down_index")
