@@ -16,7 +16,8 @@ import torch.nn.functional as F
 
 from oracle.restatement import _act, _bn, diffusion_schedule, down_block, timeembed, up_block
 from oracle.restatement import build_plan as _ddpm_plan
-from oracle.vqunet import channel_linear, is_param  # noqa: F401  (is_param re-exported for the tests)
+from oracle.vqunet import attn_block, channel_linear, is_param  # noqa: F401  (the attention block of models/ldm.py:91-108 is
+#                                                                  the one of models/vqvaeunet.py:83-100; is_param for the tests)
 
 
 def build_plan(cfg):
@@ -37,16 +38,6 @@ def resnet_block(sd, pfx, x, temb, training, p_drop, drop_mask=None):
     h = F.conv2d(a, sd[pfx + ".block2.0.3.weight"], sd[pfx + ".block2.0.3.bias"], padding=1)
     if pfx + ".layers.0.linear.weight" in sd:
         x = channel_linear(sd, pfx + ".layers.0", x)
-    return x + h
-
-
-def attn_block(sd, pfx, x, training):
-    """Attention between channels; reference models/ldm.py:98-108: one projection serves as q, k and v."""
-    B, C, H, W = x.shape
-    h = _bn(sd, pfx + ".norm", x, training)
-    p = channel_linear(sd, pfx + ".linear1", h).reshape(B, C, H * W)
-    w = torch.softmax(torch.matmul(p, p.transpose(-2, -1)) * (C ** -0.5), dim=-1)
-    h = channel_linear(sd, pfx + ".linear2", torch.matmul(w, p).reshape(B, C, H, W))
     return x + h
 
 

@@ -29,8 +29,9 @@ BASE = dict(name="vqvaeunet", learning_rate=1e-3, manual_seed=42, sampling_perio
 CONFIGS = {
     # a level without resampling in the middle (the butterfly arrangement): in == out and in != out blocks both ways
     "v0": dict(BASE, h_dims=[3, 32, 32, 64], down_index=[0, 1, 0, 1], patch_size=16, num_embed=64, embed_dim=64),
-    # resampling at every level, odd batch
-    "v1": dict(BASE, h_dims=[3, 32, 64], down_index=[0, 1, 1], patch_size=16, num_embed=48, embed_dim=64),
+    # resampling at every level, odd batch, an AttnBlock on each side at the one level whose block keeps the channel count
+    # (at any other level the reference's `h += skip[index]` meets tensors of different widths and fails)
+    "v1": dict(BASE, h_dims=[3, 32, 32, 64], down_index=[0, 1, 1, 1], patch_size=16, num_embed=48, embed_dim=64, attn_res=[8]),
 }
 BATCH = {"v0": 4, "v1": 3}
 

@@ -20,7 +20,8 @@ BETA = 0.25             # VQBlock default, reference models/vqvaeunet.py:106
 
 
 def build_plan(cfg) -> Dict[str, List[tuple]]:
-    """Module sequence, from reference models/vqvaeunet.py:164-203: ('res', cin, cout) | ('down', c) | ('up', c)."""
+    """Module sequence, from reference models/vqvaeunet.py:164-203: ('res', cin, cout) | ('attn', c) | ('down', c) |
+    ('up', c)."""
     h = list(cfg["h_dims"])
     di = list(cfg["down_index"])
     attn = list(cfg["attn_res"])
@@ -30,7 +31,8 @@ def build_plan(cfg) -> Dict[str, List[tuple]]:
     for i in range(len(h) - 1):
         cin, cout = h[i], h[i + 1]
         down.append(("res", cin, cout))
-        assert res not in attn, "the channel-attention block (models/vqvaeunet.py:83-100) is not restated"
+        if res in attn:
+            down.append(("attn", cout))
         if di[i + 1] == 1:
             down.append(("down", cout))
             res = res / 2
@@ -41,7 +43,8 @@ def build_plan(cfg) -> Dict[str, List[tuple]]:
             up.append(("up", cin))
             res = res * 2
         up.append(("res", cin, cout))
-        assert res not in attn
+        if res in attn:
+            up.append(("attn", cout))
     return {"down": down, "up": up, "end": cout}
 
 
@@ -63,6 +66,15 @@ def resnet_block(sd, pfx, x, training):
     if pfx + ".layers.0.linear.weight" in sd:
         x = channel_linear(sd, pfx + ".layers.0", x)
     return x + h
+
+
+def attn_block(sd, pfx, x, training):
+    """Attention between channels; reference models/vqvaeunet.py:90-100: one projection serves as q, k and v."""
+    B, C, H, W = x.shape
+    h = _bn(sd, pfx + ".norm", x, training)
+    p = channel_linear(sd, pfx + ".linear1", h).reshape(B, C, H * W)
+    w = torch.softmax(torch.matmul(p, p.transpose(-2, -1)) * (C ** -0.5), dim=-1)
+    return x + channel_linear(sd, pfx + ".linear2", torch.matmul(w, p).reshape(B, C, H, W))
 
 
 def vq_block(weight, latents, beta=BETA):
@@ -88,6 +100,8 @@ def forward(sd, cfg, x, training=False, taps=None):
     def run(pfx, m, h):
         if m[0] == "res":
             h = resnet_block(sd, pfx, h, training)
+        elif m[0] == "attn":
+            h = attn_block(sd, pfx, h, training)
         elif m[0] == "down":
             h = down_block(sd, pfx, h)
         else:

@@ -115,7 +115,9 @@ def test_configuration_errors():
         del bad[k]
         with pytest.raises(KeyError):
             make_vq_plan(bad)
-    with pytest.raises(NotImplementedError):
-        make_vq_plan(dict(cfg, attn_res=[8]))
+    # an AttnBlock where attn_res lists the resolution: before the level's DownBlock, after the level's UpBlock
+    plan = make_vq_plan(dict(cfg, attn_res=[8]))
+    assert [l.kind for l in plan.section("Downsampling")] == ["res", "down", "res", "attn", "down"]
+    assert [l.kind for l in plan.section("Upsampling")] == ["up", "res", "attn", "up", "res"]
     with pytest.raises(ValueError):
         make_vq_plan(dict(cfg, embed_dim=32))

@@ -180,6 +180,12 @@ def test_refuses_what_it_cannot_do(case):
         m(x)
     with pytest.raises(ValueError, match="encoder outputs"):
         m.decode(torch.zeros(1, cfg["embed_dim"], 4, 4, device=DEV), [])
+    # an AttnBlock at a level whose block changes the channel count: the decoder's block output (32 channels) meets the
+    # encoder's (64) in `h += skip[index]`; the reference fails on the shapes there, this engine before the launch
+    bad = dict(cfg, h_dims=[3, 32, 64], down_index=[0, 1, 1], attn_res=[8], embed_dim=64)
+    mb = vision_amd.get_model("vqvaeunet", bad, compute_dtype=torch.float32).to(DEV).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="do not mirror"):
+        mb(g["x"].to(DEV))
 
 
 # ------------------------------------------------------------------ the two kernels this model adds

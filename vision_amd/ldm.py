@@ -29,7 +29,7 @@ from .engine import LatentEngine
 from .lightning_shim import LightningModule
 from .plan import make_ldm_plan
 from .utils import save_image_grid
-from .vqvaeunet import _ChannelLinear
+from .vqvaeunet import _AttnParams, _ChannelLinear      # the same block in both files (models/ldm.py:91-96)
 
 
 class _ResParams(nn.Module):
@@ -43,16 +43,6 @@ class _ResParams(nn.Module):
         self.block2 = nn.ModuleList([nn.Sequential(nn.BatchNorm2d(cout), act, nn.Dropout(dropout),
                                                    _conv(cout, cout, 3, padding=1))])
         self.layers = nn.ModuleList([_ChannelLinear(cin, cout)]) if cin != cout else None
-
-
-class _AttnParams(nn.Module):
-    """reference models/ldm.py:91-96."""
-
-    def __init__(self, c):
-        super().__init__()
-        self.linear1 = _ChannelLinear(c, c)
-        self.linear2 = _ChannelLinear(c, c)
-        self.norm = nn.BatchNorm2d(c)
 
 
 class LatentDiffusion(DDPMModel):

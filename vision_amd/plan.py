@@ -114,8 +114,9 @@ VQ_REQUIRED_KEYS = ("h_dims", "patch_size", "num_embed", "embed_dim", "sampling_
 
 
 def make_vq_plan(config) -> UNetPlan:
-    """Layer plan of the VQ-VAE-UNet first stage (reference models/vqvaeunet.py:150-203): per level a ResNetBlock and,
-    where down_index says so, a DownBlock; mirrored by UpBlock + ResNetBlock per level; the codebook lookup sits between
+    """Layer plan of the VQ-VAE-UNet first stage (reference models/vqvaeunet.py:150-203): per level a ResNetBlock, an
+    AttnBlock where the resolution is listed in attn_res and, where down_index says so, a DownBlock; mirrored by UpBlock
+    + ResNetBlock (+ AttnBlock) per level; the codebook lookup sits between
     the two halves, the channel-wise Linear + Sigmoid head after them.  The blocks take no time embedding
     (time_features = 0) and always resample with convolutions (models/vqvaeunet.py:161)."""
     for k in VQ_REQUIRED_KEYS:
@@ -127,13 +128,6 @@ def make_vq_plan(config) -> UNetPlan:
     levels = len(dims) - 1
     layers: List[LayerSpec] = []
 
-    def no_attention(res):
-        # the reference's test is `f_res in attn_res` on a value that is a float after the first halving
-        if res in attn_at:
-            raise NotImplementedError(
-                f"attn_res {attn_at} puts an AttnBlock at resolution {res}: the first stage's channel-attention block "
-                "(models/vqvaeunet.py:83-100) is not built; neither shipped configuration instantiates it")
-
     res = config["patch_size"]
     pos = 0
     width = dims[0]
@@ -141,7 +135,9 @@ def make_vq_plan(config) -> UNetPlan:
         width_in, width = dims[lvl], dims[lvl + 1]
         layers.append(LayerSpec("Downsampling", pos, "res", width_in, width, int(res), int(res)))
         pos += 1
-        no_attention(res)                                        # checked before the level's DownBlock
+        if res in attn_at:                                       # checked before the level's DownBlock; `f_res in
+            layers.append(LayerSpec("Downsampling", pos, "attn", width, width, int(res), int(res)))   # attn_res` on a float
+            pos += 1
         if down_flags[lvl + 1] == 1:
             layers.append(LayerSpec("Downsampling", pos, "down", width, width, int(res), (int(res) - 1) // 2 + 1))
             pos += 1
@@ -159,6 +155,8 @@ def make_vq_plan(config) -> UNetPlan:
             res = res * 2
         layers.append(LayerSpec("Upsampling", pos, "res", width_in, width, int(res), int(res)))
         pos += 1
-        no_attention(res)                                        # checked after the level's UpBlock
+        if res in attn_at:                                       # checked after the level's UpBlock
+            layers.append(LayerSpec("Upsampling", pos, "attn", width, width, int(res), int(res)))
+            pos += 1
     return UNetPlan(layers=layers, ch=0, time_features=0, end_channels=width,
                     patch_size=int(config["patch_size"]), with_conv=True)

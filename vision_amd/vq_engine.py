@@ -1,7 +1,8 @@
 """Execution engine of the VQ-VAE-UNet first stage (reference models/vqvaeunet.py:149-233): the UNet engine's layer
 objects, arenas and weight re-packing, with the first stage's own wiring:
 
-* ResNetBlocks without a time embedding whose 1x1 shortcut is a channel-wise nn.Linear (key `layers.0.linear`);
+* ResNetBlocks without a time embedding whose 1x1 shortcut is a channel-wise nn.Linear (key `layers.0.linear`); the
+  channel-attention block of the latent-diffusion file where attn_res asks for one;
 * EVERY encoder module's output is a skip, added to the input of the decoder module at the mirrored position
   (`h += skip[index]`, models/vqvaeunet.py:228-231) -- here by the epilogue of the kernel producing that input;
 * the codebook lookup between the two halves, in fp32 on the encoder's NHWC output (its rows are the latents, so no
@@ -13,7 +14,7 @@ from typing import Dict, List, Optional
 import torch
 
 from ._lib import call, lib
-from .engine import FUSE_EVAL_NORM, Engine, _Conv, _ResBlock, _Resample, _ptr, _stream
+from .engine import FUSE_EVAL_NORM, Engine, _ChanAttnBlock, _Conv, _ResBlock, _Resample, _ptr, _stream
 
 
 class VQUNetEngine(Engine):
@@ -26,7 +27,12 @@ class VQUNetEngine(Engine):
     def _init_layers(self, plan):
         self.layers = []
         for spec in plan.layers:
-            self.layers.append(_ResBlock(self, spec, 0) if spec.kind == "res" else _Resample(self, spec))
+            if spec.kind == "res":
+                self.layers.append(_ResBlock(self, spec, 0))
+            elif spec.kind == "attn":
+                self.layers.append(_ChanAttnBlock(self, spec))     # models/vqvaeunet.py:83-100, the block of models/ldm.py
+            else:
+                self.layers.append(_Resample(self, spec))
         self.n_enc = len(plan.section("Downsampling"))
         n_dec = len(plan.section("Upsampling"))
         head = f"Upsampling.{n_dec}"
@@ -56,6 +62,11 @@ class VQUNetEngine(Engine):
             layer = self.layers[i]
             j = i + 1 - ne
             res2 = skips[ne - 1 - j] if 1 <= j < ne else None
+            if res2 is not None and tuple(res2.shape) != self._out_shape(layer, h):
+                # the reference fails here too (`h += skip[index]` on mismatched shapes): an AttnBlock at a level whose
+                # block changes the channel count pairs encoder and decoder outputs of different widths
+                raise RuntimeError(f"skip of shape {tuple(res2.shape)} meets the output {self._out_shape(layer, h)} of "
+                                   f"{layer.spec.prefix}: encoder and decoder do not mirror each other in this configuration")
             nxt = self.layers[i + 1] if i + 1 < n and i + 1 != ne else None       # nothing is fused across the lookup
             want = training and isinstance(nxt, _ResBlock)
             nn_ = nxt.bn1 if (FUSE_EVAL_NORM and not training and tape is None and isinstance(nxt, _ResBlock)) else None
@@ -65,6 +76,15 @@ class VQUNetEngine(Engine):
             if i < ne:
                 skips.append(h)
         return h
+
+    @staticmethod
+    def _out_shape(layer, h):
+        B, H, W, _ = h.shape
+        if layer.spec.kind == "down":
+            H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        elif layer.spec.kind == "up":
+            H, W = 2 * H, 2 * W
+        return (B, H, W, layer.spec.cout)
 
     def encode(self, x, training=False, tape=None):
         """reference models/vqvaeunet.py:215-222: (encoder output, every encoder module's output), NHWC."""

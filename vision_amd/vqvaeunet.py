@@ -44,6 +44,16 @@ class _ResParams(nn.Module):
         self.layers = nn.ModuleList([_ChannelLinear(cin, cout)]) if cin != cout else None
 
 
+class _AttnParams(nn.Module):
+    """reference models/vqvaeunet.py:83-88."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.linear1 = _ChannelLinear(c, c)
+        self.linear2 = _ChannelLinear(c, c)
+        self.norm = nn.BatchNorm2d(c)
+
+
 class _DownParams(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -125,6 +135,8 @@ class VQVAEUNETModel(LightningModule):
         for spec in plan.layers:
             if spec.kind == "res":
                 m = _ResParams(spec.cin, spec.cout, self.act)
+            elif spec.kind == "attn":
+                m = _AttnParams(spec.cout)
             elif spec.kind == "down":
                 m = _DownParams(spec.cout)
             else:
