@@ -37,7 +37,25 @@ def _batch(cfg, B, rank, step):
             torch.rand((B, 1, 1, 1), generator=g))
 
 
-def _worker(rank, world, port, out_dir):
+def _setup(kind):
+    """(model on cuda:0 in fp32 compute with the fixture's initial state, config, batch, loss(model, batch tensors))."""
+    import vision_amd
+    dev = torch.device("cuda:0")
+    if kind == "ddpm":
+        t, cfg, B = load_golden("t1")
+        state = sub(t, "state0")
+        loss = lambda m, x, eps, tt: m.p_loss(x, noises=eps, diffusion_times=tt)
+    else:                                   # the first stage: codebook gradient at arena offset 0, written mid-backward
+        from test_vqunet_cpu import load_case
+        cfg, t = load_case("v0")
+        B = 4
+        state = {k[len("state/"):]: v for k, v in t.items() if k.startswith("state/")}
+        loss = lambda m, x, eps, tt: m._step_loss((x, None))
+    model = vision_amd.get_model(kind, cfg, compute_dtype="fp32").to(dev).train()
+    return model, state, cfg, B, loss
+
+
+def _worker(rank, world, port, out_dir, kind):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import vision_amd
     from vision_amd.parallel import DataParallel
@@ -45,9 +63,7 @@ def _worker(rank, world, port, out_dir):
     try:
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        t, cfg, B = load_golden("t1")
-        model = vision_amd.get_model("ddpm", cfg, compute_dtype="fp32").to(dev).train()
-        state = sub(t, "state0")
+        model, state, cfg, B, loss_of = _setup(kind)
         if rank == 1:                      # rank 1 starts from different weights: the broadcast must fix that
             state = {k: (v + 0.25 if v.dtype.is_floating_point else v) for k, v in state.items()}
         model.load_state_dict(state)
@@ -59,7 +75,7 @@ def _worker(rank, world, port, out_dir):
         for step in range(2):
             x, eps, tt = (v.to(dev) for v in _batch(cfg, B, rank, step))
             dp.broadcast_buffers()
-            loss = model.p_loss(x, noises=eps, diffusion_times=tt)
+            loss = loss_of(model, x, eps, tt)
             loss.backward()
             dp.reducer.wait()
             grads.append(eng.flat_g.clone().cpu())
@@ -71,10 +87,10 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(tmp_path):
-    import vision_amd
+@pytest.mark.parametrize("kind", ["ddpm", "vqvaeunet"])
+def test_two_ranks_match_single_process(tmp_path, kind):
     world = 2
-    ctx = mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+    ctx = mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), kind), nprocs=world, join=False)
     deadline = time.time() + 90
     while not ctx.join(timeout=5):                     # never leave the suite hanging on a stuck rank
         if time.time() > deadline:
@@ -90,9 +106,8 @@ def test_two_ranks_match_single_process(tmp_path):
 
     # single process: per-rank gradients of the same batches, averaged by hand
     dev = torch.device("cuda:0")
-    t, cfg, B = load_golden("t1")
-    model = vision_amd.get_model("ddpm", cfg, compute_dtype="fp32").to(dev).train()
-    model.load_state_dict(sub(t, "state0"))
+    model, state, cfg, B, loss_of = _setup(kind)
+    model.load_state_dict(state)
     eng = model._ensure_engine()
     opt = model.configure_optimizers()[0][0]
     bufs0 = eng.flat_b.clone()
@@ -102,7 +117,7 @@ def test_two_ranks_match_single_process(tmp_path):
         for rank in range(world):
             eng.flat_b.copy_(bufs0)                       # every rank starts the step from rank 0's buffers
             x, eps, tt = (v.to(dev) for v in _batch(cfg, B, rank, step))
-            loss = model.p_loss(x, noises=eps, diffusion_times=tt)
+            loss = loss_of(model, x, eps, tt)
             loss.backward()
             per_rank.append(eng.flat_g.clone())
             if rank == 0:
