@@ -634,11 +634,15 @@ def test_time_embedding_path():
         assert relerr(dx, gx + 1.0) < 1e-5 and relerr(dW, gw) < 1e-5 and relerr(db, gb) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 3, 10, 6), (2, 8, 5, 7), (3, 40, 7, 7), (2, 256, 7, 7)],
+                         ids=lambda v: "x".join(map(str, v)))
 @pytest.mark.parametrize("dts", ["f32", "bf16"])
-def test_diffusion_elementwise(dts):
+def test_diffusion_elementwise(dts, shape):
+    """Images (3 channels: one lane per pixel) and latents (many channels: one lane per element, tiled layout
+    converters; 40 channels and 49 positions are no multiples of the 32 x 32 tile)."""
     tdt, dt = DT[dts]
     gen = torch.Generator().manual_seed(3)
-    B, Cc, H, W = 3, 3, 10, 6
+    B, Cc, H, W = shape
     x0, eps = torch.rand((B, Cc, H, W), generator=gen), torch.randn((B, Cc, H, W), generator=gen)
     t = torch.rand(B, generator=gen)
     lo, hi = torch.acos(torch.tensor(0.95)), torch.acos(torch.tensor(0.02))

@@ -69,20 +69,25 @@ __global__ void schedule_kernel(const float* __restrict__ t, float* n, float* s,
 template <typename T>
 __global__ void qsample_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
                                const float* __restrict__ t, T* __restrict__ xt, float* n_out,
-                               float* s_out, float* n2_out, int B, int C, int64_t HW) {
-    const int64_t total = (int64_t)B * HW;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
-         p += (int64_t)gridDim.x * blockDim.x) {
+                               float* s_out, float* n2_out, int B, int C, int64_t HW, int CW) {
+    // a work item = CW channels of one pixel: all of them for thin inputs (images), one for many-channel inputs
+    // (latents), where consecutive lanes then walk the channels of the channels-last tensor
+    const int CS = (C + CW - 1) / CW;
+    const int64_t total = (int64_t)B * HW * CS;
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = w / CS;
+        const int c0 = (int)(w - p * CS) * CW, c1 = min(C, c0 + CW);
         const int b = (int)(p / HW);
         const int64_t hw = p - (int64_t)b * HW;
         float n, s;
         schedule_of(t[b], n, s);
-        if (hw == 0) {
+        if (hw == 0 && c0 == 0) {
             n_out[b] = n;
             s_out[b] = s;
             n2_out[b] = n * n;
         }
-        for (int c = 0; c < C; ++c) {
+        for (int c = c0; c < c1; ++c) {
             const int64_t src = ((int64_t)b * C + c) * HW + hw;
             const float v = s * x0[src] + n * eps[src];
             xt[p * C + c] = from_f<T>(v);
@@ -92,14 +97,17 @@ __global__ void qsample_kernel(const float* __restrict__ x0, const float* __rest
 
 template <typename T>
 __global__ void l1_fwd_kernel(const T* __restrict__ pred, const float* __restrict__ eps,
-                              float* __restrict__ partial, int B, int C, int64_t HW) {
-    const int64_t total = (int64_t)B * HW;
+                              float* __restrict__ partial, int B, int C, int64_t HW, int CW) {
+    const int CS = (C + CW - 1) / CW;                 // work items of CW channels, as in qsample_kernel
+    const int64_t total = (int64_t)B * HW * CS;
     float acc = 0.f;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
-         p += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = w / CS;
+        const int c0 = (int)(w - p * CS) * CW, c1 = min(C, c0 + CW);
         const int b = (int)(p / HW);
         const int64_t hw = p - (int64_t)b * HW;
-        for (int c = 0; c < C; ++c)
+        for (int c = c0; c < c1; ++c)
             acc += fabsf(to_f(pred[p * C + c]) - eps[((int64_t)b * C + c) * HW + hw]);
     }
     __shared__ float red[4];
@@ -121,14 +129,17 @@ __global__ void l1_finalize_kernel(const float* __restrict__ partial, int nchunk
 template <typename T>
 __global__ void l1_bwd_kernel(const T* __restrict__ pred, const float* __restrict__ eps,
                               const float* __restrict__ gout, T* __restrict__ dpred, int B, int C,
-                              int64_t HW, float inv_numel) {
-    const int64_t total = (int64_t)B * HW;
+                              int64_t HW, float inv_numel, int CW) {
+    const int CS = (C + CW - 1) / CW;
+    const int64_t total = (int64_t)B * HW * CS;
     const float g = gout[0] * inv_numel;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
-         p += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = w / CS;
+        const int c0 = (int)(w - p * CS) * CW, c1 = min(C, c0 + CW);
         const int b = (int)(p / HW);
         const int64_t hw = p - (int64_t)b * HW;
-        for (int c = 0; c < C; ++c) {
+        for (int c = c0; c < c1; ++c) {
             const float d = to_f(pred[p * C + c]) - eps[((int64_t)b * C + c) * HW + hw];
             const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);   // torch sign(): sign(0) = 0
             dpred[p * C + c] = from_f<T>(g * sg);
@@ -189,14 +200,17 @@ __global__ void denoise_step_kernel(float* __restrict__ cur, const T* __restrict
                                     const float* __restrict__ n, const float* __restrict__ s,
                                     const float* __restrict__ n_next,
                                     const float* __restrict__ s_next, T* __restrict__ next_in,
-                                    float* __restrict__ pred_images, int B, int C, int64_t HW) {
-    const int64_t total = (int64_t)B * HW;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
-         p += (int64_t)gridDim.x * blockDim.x) {
+                                    float* __restrict__ pred_images, int B, int C, int64_t HW, int CW) {
+    const int CS = (C + CW - 1) / CW;
+    const int64_t total = (int64_t)B * HW * CS;
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < total;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = w / CS;
+        const int c0 = (int)(w - p * CS) * CW, c1 = min(C, c0 + CW);
         const int b = (int)(p / HW);
         const int64_t hw = p - (int64_t)b * HW;
         const float nb = n[b], sb = s[b], nn = n_next[b], sn = s_next[b];
-        for (int c = 0; c < C; ++c) {
+        for (int c = c0; c < c1; ++c) {
             const float e = to_f(eps_hat[p * C + c]);
             const float x0h = (cur[p * C + c] - nb * e) / sb;
             const float nx = sn * x0h + nn * e;
@@ -232,6 +246,30 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__
         const int b = (int)(p / HW);
         const int64_t hw = p - (int64_t)b * HW;
         for (int c = 0; c < C; ++c) y[((int64_t)b * C + c) * HW + hw] = to_f(x[p * C + c]);
+    }
+}
+
+// Layout + dtype conversion of many-channel tensors: x [batch][R][Cc] -> y [batch][Cc][R] (and an optional fp32 copy in
+// y's layout), 32 x 32 tiles through LDS (+1 pad) so that both sides move whole rows of a tile.
+template <typename TIn, typename TOut>
+__global__ void convert_transpose_kernel(const TIn* __restrict__ x, TOut* __restrict__ y, float* __restrict__ y32, int R,
+                                         int Cc) {
+    __shared__ float tile[32][33];
+    const int64_t base = (int64_t)blockIdx.z * R * Cc;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < R && c < Cc) tile[i][tx] = to_f(x[base + (int64_t)r * Cc + c]);
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < Cc) {
+            const float v = tile[tx][i];
+            y[base + (int64_t)c * R + r] = from_f<TOut>(v);
+            if (y32) y32[base + (int64_t)c * R + r] = v;
+        }
     }
 }
 
@@ -745,14 +783,20 @@ int vamd_schedule(const float* t, float* n, float* s, float* n2, int B, void* st
     return 0;
 }
 
+// Channels per work item of the kernels at the model boundary: a pixel's whole channel vector for thin tensors (images:
+// the NCHW side is then read plane by plane with consecutive lanes on consecutive pixels), single channels otherwise.
+static int chan_width(int C) { return C <= 8 ? C : 1; }
+static int64_t chan_slices(int C) { return (C + chan_width(C) - 1) / chan_width(C); }
+constexpr int kTiledConvertMinC = 16;
+
 int vamd_qsample(const float* x0, const float* eps, const float* t, void* xt, float* n, float* s,
                  float* n2, int B, int C, int H, int W, int dtype, void* stream) {
     VAMD_REQUIRE(x0 && eps && t && xt && n && s && n2, "vamd_qsample: null pointer");
     VAMD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "vamd_qsample: bad shape %d %d %d %d", B, C, H, W);
     const int64_t HW = (int64_t)H * W;
     VAMD_DISPATCH(dtype, "vamd_qsample", {
-        hipLaunchKernelGGL(qsample_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
-                           as_stream(stream), x0, eps, t, (T*)xt, n, s, n2, B, C, HW);
+        hipLaunchKernelGGL(qsample_kernel<T>, dim3(grid_for(B * HW * chan_slices(C), 256)), dim3(256), 0,
+                           as_stream(stream), x0, eps, t, (T*)xt, n, s, n2, B, C, HW, chan_width(C));
     });
     VAMD_LAUNCH_OK("vamd_qsample");
     return 0;
@@ -768,7 +812,7 @@ int vamd_l1_loss_fwd(const void* pred, const float* eps, float* partial, float* 
     const int nchunk = vamd_l1_chunks(B * HW);
     VAMD_DISPATCH(dtype, "vamd_l1_loss_fwd", {
         hipLaunchKernelGGL(l1_fwd_kernel<T>, dim3(nchunk), dim3(256), 0, as_stream(stream),
-                           (const T*)pred, eps, partial, B, C, HW);
+                           (const T*)pred, eps, partial, B, C, HW, chan_width(C));
     });
     hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), partial, nchunk,
                        1.0 / ((double)B * C * HW), loss);
@@ -782,9 +826,9 @@ int vamd_l1_loss_bwd(const void* pred, const float* eps, const float* gout, void
     VAMD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "vamd_l1_loss_bwd: bad shape");
     const int64_t HW = (int64_t)H * W;
     VAMD_DISPATCH(dtype, "vamd_l1_loss_bwd", {
-        hipLaunchKernelGGL(l1_bwd_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
+        hipLaunchKernelGGL(l1_bwd_kernel<T>, dim3(grid_for(B * HW * chan_slices(C), 256)), dim3(256), 0,
                            as_stream(stream), (const T*)pred, eps, gout, (T*)dpred, B, C, HW,
-                           (float)(1.0 / ((double)B * C * HW)));
+                           (float)(1.0 / ((double)B * C * HW)), chan_width(C));
     });
     VAMD_LAUNCH_OK("vamd_l1_loss_bwd");
     return 0;
@@ -827,9 +871,9 @@ int vamd_denoise_step(float* cur, const void* eps_hat, const float* n, const flo
     VAMD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "vamd_denoise_step: bad shape");
     const int64_t HW = (int64_t)H * W;
     VAMD_DISPATCH(dtype, "vamd_denoise_step", {
-        hipLaunchKernelGGL(denoise_step_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
+        hipLaunchKernelGGL(denoise_step_kernel<T>, dim3(grid_for(B * HW * chan_slices(C), 256)), dim3(256), 0,
                            as_stream(stream), cur, (const T*)eps_hat, n, s, n_next, s_next,
-                           (T*)next_in, pred_images, B, C, HW);
+                           (T*)next_in, pred_images, B, C, HW, chan_width(C));
     });
     VAMD_LAUNCH_OK("vamd_denoise_step");
     return 0;
@@ -839,6 +883,15 @@ int vamd_nchw_to_nhwc(const float* x, void* y, float* y32, int B, int C, int H, 
                       void* stream) {
     VAMD_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "vamd_nchw_to_nhwc: bad argument");
     const int64_t HW = (int64_t)H * W;
+    if (C >= kTiledConvertMinC && B <= 65535 && (C + 31) / 32 <= 65535) {       // x [B][C][HW] -> y [B][HW][C]
+        const dim3 grid((unsigned)((HW + 31) / 32), (C + 31) / 32, B);
+        VAMD_DISPATCH(dtype, "vamd_nchw_to_nhwc", {
+            hipLaunchKernelGGL((convert_transpose_kernel<float, T>), grid, dim3(256), 0, as_stream(stream), x, (T*)y, y32, C,
+                               (int)HW);
+        });
+        VAMD_LAUNCH_OK("vamd_nchw_to_nhwc");
+        return 0;
+    }
     VAMD_DISPATCH(dtype, "vamd_nchw_to_nhwc", {
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
                            as_stream(stream), x, (T*)y, y32, B, C, HW);
@@ -850,6 +903,15 @@ int vamd_nchw_to_nhwc(const float* x, void* y, float* y32, int B, int C, int H, 
 int vamd_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int dtype, void* stream) {
     VAMD_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "vamd_nhwc_to_nchw: bad argument");
     const int64_t HW = (int64_t)H * W;
+    if (C >= kTiledConvertMinC && B <= 65535 && (HW + 31) / 32 <= 65535) {      // x [B][HW][C] -> y [B][C][HW]
+        const dim3 grid((C + 31) / 32, (unsigned)((HW + 31) / 32), B);
+        VAMD_DISPATCH(dtype, "vamd_nhwc_to_nchw", {
+            hipLaunchKernelGGL((convert_transpose_kernel<T, float>), grid, dim3(256), 0, as_stream(stream), (const T*)x, y,
+                               (float*)nullptr, (int)HW, C);
+        });
+        VAMD_LAUNCH_OK("vamd_nhwc_to_nchw");
+        return 0;
+    }
     VAMD_DISPATCH(dtype, "vamd_nhwc_to_nchw", {
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(grid_for(B * HW, 256)), dim3(256), 0,
                            as_stream(stream), (const T*)x, y, B, C, HW);

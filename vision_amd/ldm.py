@@ -140,7 +140,7 @@ class LatentDiffusion(DDPMModel):
         was = fs.training
         fs.eval()
         try:
-            z, _ = fs.encode(x)
+            z = fs.encode_latents(x)
         finally:
             fs.train(was)
         return z

@@ -200,6 +200,14 @@ class VQVAEUNETModel(LightningModule):
         return self._nchw(h), [self._nchw(s) for s in skips]
 
     @torch.no_grad()
+    def encode_latents(self, x):
+        """The encoder output alone (what a latent-diffusion model trains on), NCHW fp32: encode() without the
+        layout conversion of every skip."""
+        eng = self._ensure_engine()
+        h, _ = eng.encode(self._nhwc(x), self.training)
+        return self._nchw(h)
+
+    @torch.no_grad()
     def quantize(self, h):
         """The codebook lookup on NCHW latents: (quantised latents NCHW fp32, vq_loss, codes [B, H, W] int64)."""
         eng = self._ensure_engine()
