@@ -97,6 +97,8 @@ class VQUNetEngine(Engine):
         `h` may be fp32 (the codebook lookup's output) or the compute dtype; the first skip is added here."""
         if len(skips) != self.n_enc:
             raise ValueError(f"decode() needs the {self.n_enc} encoder outputs, got {len(skips)}")
+        if tape is None:
+            self._begin(training)          # a call of its own (inference): weights may have changed since the last encode
         last = skips[-1]
         if h.shape != last.shape:
             raise ValueError(f"latents {tuple(h.shape)} do not match the encoder output {tuple(last.shape)}")
