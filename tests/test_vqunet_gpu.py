@@ -325,3 +325,30 @@ def test_run_flow_of_the_first_stage(tmp_path, capsys):
     out = capsys.readouterr().out
     assert logger2.version == 1 and "Loaded checkpoint from" in out
     assert all(torch.equal(last[k], v.detach().cpu()) for k, v in model2.state_dict().items())
+
+
+def test_eval_mode_gradients(case):
+    """model.eval() followed by loss.backward(): BatchNorm uses its running statistics, so its input gradient has no mean /
+    variance terms and the biases in front of it (zero gradient in training mode) are live; against the oracle in eval mode."""
+    name, cfg, g = case
+    sd = sub(g, "after/")
+    m = make_model(cfg, sd, torch.float32).eval()
+    loss = m._step_loss((g["x2"].to(DEV), None))
+    loss.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if O.is_param(k)}
+    work = {k: v.clone() for k, v in sd.items()}
+    work.update(leaves)
+    total, _, _, _, idx = O.loss(work, cfg, g["x2"], False)
+    want = dict(zip(leaves, torch.autograd.grad(total, list(leaves.values()), allow_unused=True)))
+    assert torch.equal(m._ensure_engine().last_indices.cpu(), idx)
+    assert abs(loss.item() - total.item()) <= 1e-5 * total.item()
+    got = {k: p.grad for k, p in m.named_parameters()}
+    for k, w in want.items():
+        w = torch.zeros_like(leaves[k]) if w is None else w
+        assert rel(got[k], w) <= 5e-4, (k, rel(got[k], w))
+    k1 = next(k for k in want if k.endswith(".block1.0.2.bias"))
+    assert want[k1].abs().max().item() > 0
+    # the running statistics did not move
+    for k, v in sd.items():
+        if "running_" in k:
+            assert torch.equal(m.state_dict()[k].cpu(), v), k
