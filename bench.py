@@ -1,6 +1,6 @@
 """Benchmark of the DDPM UNet training step (and sampler) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--preset butterfly|flowers|ffhq] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--preset butterfly|flowers|ffhq|vqvaeunet|ldm] [--batch B]
 
 One "step" = one full training step of the hot path on one synthetic ImageFolder-shaped batch per
 GPU: schedule + q_sample, UNet forward, L1 loss, hand-written backward, (bucketed RCCL gradient
@@ -148,10 +148,15 @@ def main():
 
     preset = get_preset(args.preset)
     cfg = preset["model_config"]
+    kind = cfg["name"]                   # 'ddpm' | 'vqvaeunet' (first stage) | 'ldm' (latent diffusion over the first stage)
     B = args.batch or preset["data_config"]["batch_size"]
-    P = cfg["patch_size"]
+    P = preset["data_config"]["patch_size"]
     torch.manual_seed(cfg["manual_seed"])
-    model = vision_amd.get_model("ddpm", cfg, compute_dtype=args.dtype).to(dev).train()
+    model = vision_amd.get_model(kind, cfg, compute_dtype=args.dtype).to(dev).train()
+    if kind == "ldm":
+        # image batches in, the first stage's encoder inside the timed step (frozen, random-init like everything here)
+        fs_cfg = get_preset("vqvaeunet")["model_config"]
+        model.set_first_stage(vision_amd.get_model("vqvaeunet", fs_cfg, compute_dtype=args.dtype).to(dev).eval())
     trace("model on device")
     dp = DataParallel(model)
     trace("parameters and buffers broadcast")
@@ -174,7 +179,8 @@ def main():
     for i in range(args.warmup):
         step(i)
         trace(f"warmup step {i} issued")
-    model.train_losses.clear()
+    if hasattr(model, "train_losses"):
+        model.train_losses.clear()
 
     def fence():
         torch.cuda.synchronize()
@@ -253,10 +259,11 @@ def main():
     extra["host_issue_ms_per_step"] = round(1e3 * host_elapsed / args.steps, 3)
 
     sampling = None
-    if not args.no_sampling:
+    if not args.no_sampling and kind != "vqvaeunet":
         model.eval()
         nimg = min(B, 16)
-        noise = torch.randn((nimg, 3, P, P), device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank))
+        shape = (nimg, 3, P, P) if kind == "ddpm" else (nimg, cfg["h_dims"][0], cfg["in_res"], cfg["in_res"])
+        noise = torch.randn(shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + rank))
         model.generate(nimg, 2, initial_noise=noise)
         fence()
         t1 = time.perf_counter()
@@ -267,15 +274,28 @@ def main():
                     "images_per_gpu": nimg, "image_steps_per_s": round(world * nimg * args.sample_steps / ts, 2)}
 
     if rank == 0:
-        from vision_amd.flops import train_flops_per_image
-        tf = train_flops_per_image(cfg)
+        from vision_amd import flops
+        if kind == "ddpm":
+            tf = flops.train_flops_per_image(cfg)
+            metric = "DDPM UNet train images/s (butterfly_ddpm UNet, 224x224, bf16)" if args.preset == "butterfly" \
+                else f"DDPM UNet train images/s ({args.preset}_ddpm)"
+            what = f"configs/{args.preset}_ddpm.yaml UNet training step"
+        elif kind == "vqvaeunet":
+            tf = flops.first_stage_train_flops_per_image(cfg)
+            metric = "VQ-VAE-UNet first stage train images/s (butterfly_vqvaeunet)"
+            what = "configs/butterfly_vqvaeunet.yaml first-stage training step"
+        else:
+            # the latent UNet's step plus the first stage's encoder forward (a third of its forward + backward, halved again:
+            # the decoder half does not run) -- counted as the latent UNet alone, the encoder's work is not credited
+            tf = flops.latent_train_flops_per_image(cfg)
+            metric = "Latent diffusion train images/s (butterfly_ldm over the butterfly_vqvaeunet first stage)"
+            what = "configs/butterfly_ldm.yaml latent UNet training step on the encoder output of configs/butterfly_vqvaeunet.yaml"
         out = {
-            "metric": "DDPM UNet train images/s (butterfly_ddpm UNet, 224x224, bf16)" if args.preset == "butterfly"
-            else f"DDPM UNet train images/s ({args.preset}_ddpm)",
+            "metric": metric,
             "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"configs/{args.preset}_ddpm.yaml UNet training step, per-GPU batch {B}, "
+            "config": {"workload": f"{what}, per-GPU batch {B}, "
                                    f"{P}x{P}, synthetic ImageFolder-shaped images, random-init weights (seed 42)",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "train_tflops_per_s": round(ips * tf / 1e12, 1),

@@ -1,16 +1,16 @@
-"""Algorithmic FLOP counts (2 x multiply-adds) of the UNet, from the layer plan."""
-from .plan import make_plan
+"""Algorithmic FLOP counts (2 x multiply-adds) of the UNets, from their layer plans."""
+from .plan import make_ldm_plan, make_plan, make_vq_plan
 
 
 def conv_flops(cin, cout, k, ho, wo):
     return 2.0 * cin * cout * k * k * ho * wo
 
 
-def forward_flops_per_image(config):
+def forward_flops_per_image(config, plan=None, channel_attention=False):
     """(total, first_layer_dgrad) where first_layer_dgrad is the part of the input gradient that
-    is never needed (the two convs that read the network input)."""
-    plan = make_plan(config)
-    res = config["patch_size"]
+    is never needed (the two convs that read the network input).  Default: the DDPM plan of `config`."""
+    plan = plan or make_plan(config)
+    res = plan.patch_size
     total, skip = 0.0, 0.0
     first = True
     for spec in plan.layers:
@@ -22,6 +22,10 @@ def forward_flops_per_image(config):
             if first:
                 skip = f1 + sc
                 first = False
+        elif spec.kind == "attn" and channel_attention:
+            # one shared projection + the output projection, scores [C, C] over the positions and their product with p
+            s = res * res
+            total += 2 * conv_flops(spec.cout, spec.cout, 1, res, res) + 2 * (2.0 * spec.cout * spec.cout * s)
         elif spec.kind == "attn":
             s = res * res
             total += 4 * conv_flops(spec.cout, spec.cout, 1, res, res) + 2 * (2.0 * s * s * spec.cout)
@@ -38,4 +42,19 @@ def forward_flops_per_image(config):
 def train_flops_per_image(config):
     """forward + input gradient + weight gradient = 3 x forward minus the unneeded input gradient."""
     total, skip = forward_flops_per_image(config)
+    return 3.0 * total - skip
+
+
+def first_stage_train_flops_per_image(config):
+    """VQ-VAE-UNet (reference models/vqvaeunet.py): convolutions and channel-wise linears as above, plus the codebook
+    distances 2 K D per latent vector (forward only: the lookup's gradients are gathers)."""
+    plan = make_vq_plan(config)
+    total, skip = forward_flops_per_image(config, plan, channel_attention=True)
+    latents = plan.section("Downsampling")[-1].res_out ** 2
+    return 3.0 * total - skip + 2.0 * config["num_embed"] * config["embed_dim"] * latents
+
+
+def latent_train_flops_per_image(config):
+    """The latent-space UNet of reference models/ldm.py on one latent map."""
+    total, skip = forward_flops_per_image(config, make_ldm_plan(config), channel_attention=True)
     return 3.0 * total - skip

@@ -33,6 +33,27 @@ PRESETS = {
 }
 
 
+# the first stage the reference ships (configs/butterfly_vqvaeunet.yaml) and a latent-diffusion model over its 256 x 7 x 7
+# latents (the reference has no YAML for models/ldm.py; configs/butterfly_ldm.yaml is this dict)
+PRESETS["vqvaeunet"] = {
+    "model_config": dict(name="vqvaeunet", learning_rate=1e-3, manual_seed=42, h_dims=[3, 64, 64, 128, 128, 256, 256],
+                         down_index=[0, 1, 0, 1, 1, 1, 1], patch_size=224, sampling_period=1, embed_dim=256, num_embed=2048,
+                         attn_res=[7], weight_decay=1e-3, scheduler_gamma=0.99),
+    "data_config": dict(data_dir="data/butterfly", batch_size=16, patch_size=224, num_workers=4, use_manual_split=True),
+    "trainer_config": dict(accelerator="gpu", devices=1, max_epochs=500, precision="16-mixed"),
+    "log_config": dict(name="butterfly_vqvaeunet", save_dir="logs/", check_dir="logs/check", checkpoint=True,
+                       model_summary=False),
+}
+PRESETS["ldm"] = {
+    "model_config": dict(name="ldm", learning_rate=1e-4, manual_seed=42, with_conv=True, dropout=0.1, scheduler_gamma=0.99,
+                         h_dims=[256, 256, 256], down_index=[0, 0, 0], attn_res=[7], in_res=7, sampling_period=20,
+                         weight_decay=1e-5, diffusion_steps=50, grid=2),
+    "data_config": dict(patch_size=224, data_dir="data/butterfly", batch_size=64, num_workers=4, use_manual_split=True),
+    "trainer_config": dict(accelerator="gpu", devices=1, max_epochs=2000, precision="16-mixed"),
+    "log_config": dict(name="butterfly_ldm", save_dir="logs/", check_dir="logs/check", checkpoint=False, model_summary=False),
+}
+
+
 def get_preset(name):
     return copy.deepcopy(PRESETS[name])
 
