@@ -1314,8 +1314,8 @@ template <int ROWB> __device__ __forceinline__ int tn_swizzle(int row) {
     else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;      // ROWB = odd multiple of 128
 }
 
-template <typename T, int AN, int BF>
-__global__ void __launch_bounds__(256, 2)
+template <typename T, int AN, int BF, int NW = 4, bool PIPE = false>   // NW waves: 4 (two workgroups per CU) or 8 (one)
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
 conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x, int N, int lda, int ldc,
                     float* __restrict__ dw, int n_tiles, int f_tiles, int steps_per_slice,
                     int64_t strideA, int64_t strideB, int64_t strideC, int out_mode, void* yout,
@@ -1327,10 +1327,11 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     constexpr int PPR_A = ROWB_A / 16, PPR_B = ROWB_B / 16;
     constexpr int TILE_A = KP * ROWB_A, TILE_B = KP * ROWB_B;
     constexpr int STAGE = TILE_A + TILE_B;
-    constexpr int NPASS_A = KP * PPR_A / 256, NPASS_B = KP * PPR_B / 256;
-    constexpr int WM = AN / 64, WN = 4 / WM;              // waves along n / along f
+    constexpr int NT = 64 * NW;                           // threads
+    constexpr int NPASS_A = KP * PPR_A / NT, NPASS_B = KP * PPR_B / NT;
+    constexpr int WM = AN / 64, WN = NW / WM;             // waves along n / along f
     constexpr int NJ = BF / (16 * WN);                    // 16-wide f tiles per wave
-    static_assert(KP * PPR_A % 256 == 0 && KP * PPR_B % 256 == 0 && BF % (16 * WN) == 0, "tile shape");
+    static_assert(KP * PPR_A % NT == 0 && KP * PPR_B % NT == 0 && BF % (16 * WN) == 0 && NW % WM == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1345,7 +1346,7 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     dy += (int64_t)blockIdx.z * strideA;
     x += (int64_t)blockIdx.z * strideB;
 
-    // staging: in pass i this thread copies LDS piece i*256 + tid (the image of a direct-to-LDS
+    // staging: in pass i this thread copies LDS piece i*NT + tid (the image of a direct-to-LDS
     // load is lane-linear); the swizzle is applied to the piece it fetches.  The pixel a pass reads
     // advances by KP per K-step, so its (image, row, column) and its dY offset are carried along
     // with adds and single-wrap compares; nothing is divided inside the loop.
@@ -1360,7 +1361,7 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     int a_row[NPASS_A], a_off[NPASS_A];                   // a_row >= 2^30: nothing to fetch
 #pragma unroll
     for (int i = 0; i < NPASS_A; ++i) {
-        const int pi = i * 256 + tid;
+        const int pi = i * NT + tid;
         const int row = pi / PPR_A, slot = pi - row * PPR_A;
         const int piece = BF16 ? (slot ^ tn_swizzle<ROWB_A>(row)) : slot;
         const int an = n0 + piece * PIECE;
@@ -1370,7 +1371,7 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
     int b_row[NPASS_B], b_tr[NPASS_B], b_ts[NPASS_B], b_c[NPASS_B], b_img[NPASS_B], b_ho[NPASS_B], b_wo[NPASS_B];
 #pragma unroll
     for (int i = 0; i < NPASS_B; ++i) {
-        const int pi = i * 256 + tid;
+        const int pi = i * NT + tid;
         const int row = pi / PPR_B, slot = pi - row * PPR_B;
         const int piece = BF16 ? (slot ^ tn_swizzle<ROWB_B>(row)) : slot;
         const int bf = f0 + piece * PIECE;                // flattened column -> (tap, c)
@@ -1395,7 +1396,7 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
         unsigned char* sa = smem + buf * STAGE + wave_s * 1024;
 #pragma unroll
         for (int i = 0; i < NPASS_A; ++i) {
-            load16_lds(rdy, (uint32_t)a_off[i] * (uint32_t)sizeof(T), a_row[i] < mleft, sa + i * 4096);
+            load16_lds(rdy, (uint32_t)a_off[i] * (uint32_t)sizeof(T), a_row[i] < mleft, sa + i * (NT * 16));
             a_off[i] += KP * lda;
         }
     };
@@ -1408,7 +1409,7 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
             const bool ok = (b_row[i] < mleft) & ((unsigned)u < (unsigned)gp.He) & ((unsigned)v < (unsigned)gp.We);
             const uint32_t pix = __umul24(__umul24((uint32_t)b_img[i], (uint32_t)gp.Hin) + (uint32_t)(u >> gp.shift), (uint32_t)gp.Win) +
                                  (uint32_t)(v >> gp.shift);
-            load16_lds(rxg, (pix * (uint32_t)gp.ldx + (uint32_t)b_c[i]) * (uint32_t)sizeof(T), ok, sb + i * 4096);
+            load16_lds(rxg, (pix * (uint32_t)gp.ldx + (uint32_t)b_c[i]) * (uint32_t)sizeof(T), ok, sb + i * (NT * 16));
             // advance this pass by KP pixels
             int wo = b_wo[i] + kr_w;
             const int cw = wo >= gp.Wo ? 1 : 0;
@@ -1482,6 +1483,27 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
         } else {
             static_assert(NJ == 3 || NJ == 4, "fragment wait is written for 3 or 4 column tiles");
             asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
+                           "+v"(rb[2][0]), "+v"(rb[2][1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            a[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(ra[i][0], ra[i][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            b[j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(rb[j][0], rb[j][1], 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // as frag_wait, but lets the 8 + 2 * NJ reads issued after these stay in flight (the counter holds at most 15)
+    auto frag_wait_first = [&](s16x4_t (&ra)[4][2], s16x4_t (&rb)[NJ][2], bf16x8_t (&a)[4], bf16x8_t (&b)[NJ]) {
+        if constexpr (NJ == 4) {
+            asm volatile("s_waitcnt lgkmcnt(15)"
+                         : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
+                           "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
+                           "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1]));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(14)"
                          : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(ra[2][0]), "+v"(ra[2][1]),
                            "+v"(ra[3][0]), "+v"(ra[3][1]), "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]),
                            "+v"(rb[2][0]), "+v"(rb[2][1]));
@@ -1580,11 +1602,22 @@ conv_tn_mfma_kernel(Gather gp, const T* __restrict__ dy, const T* __restrict__ x
                 stage_a(nxt);
                 stage_b(nxt);
 #endif
-                frag_wait(ra, rb, a, b);
-                mma(a, b);
-                read_frags(cur, std::integral_constant<int, 1>{}, ra, rb);
-                frag_wait(ra, rb, a, b);
-                mma(a, b);
+                if constexpr (PIPE) {
+                    // the second half's fragment reads are in flight during the first half's MFMAs: LDS reads return in
+                    // order, so once at most as many are outstanding as the second half issued, the first half has landed
+                    s16x4_t ra2[4][2], rb2[NJ][2];
+                    read_frags(cur, std::integral_constant<int, 1>{}, ra2, rb2);
+                    frag_wait_first(ra, rb, a, b);
+                    mma(a, b);
+                    frag_wait(ra2, rb2, a, b);
+                    mma(a, b);
+                } else {
+                    frag_wait(ra, rb, a, b);
+                    mma(a, b);
+                    read_frags(cur, std::integral_constant<int, 1>{}, ra, rb);
+                    frag_wait(ra, rb, a, b);
+                    mma(a, b);
+                }
             } else {
                 stage_a(nxt);
                 stage_b(nxt);
@@ -2456,17 +2489,39 @@ bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype) {
     return tn_shape_ok(g.Cin, g.Cout, g.M, dtype);
 }
 
-// Pixel slices of the weight gradient: two workgroups per CU in all (each slice runs long and the partial buffer
-// stays small); at least 8 K-steps per slice, every slice non-empty.
-static int tn_slice_cap(int tiles) {
+// Tile shape the weight-gradient launcher picks.  Narrow outputs (Cout <= 64) take a 64 x 192 tile, which wastes no
+// MFMA rows and divides 9 * Cin; everything else 128 x 128 on four waves, two workgroups per CU.  Opt-in
+// (VAMD_TN_WIDE=1 / 2): 128 x 256 or 256 x 128 on eight waves, one workgroup per CU -- 25 % fewer bytes from L2 into LDS
+// per FLOP, yet measured 5-8 % SLOWER per layer (512 -> 512 at 28 x 28 x 64: 347 vs 320 us; 256 -> 256 at 56 x 56: 304 vs
+// 288 us; step 19.80 vs 19.72 ms): two independent four-wave workgroups drift apart and hide each other's barriers
+// and fragment-read latency, one eight-wave workgroup cannot.
+struct TnShape { int AN, BF, NW; };
+static int tn_wide_mode() {
+    static const int v = [] { const char* e = getenv("VAMD_TN_WIDE"); return e ? atoi(e) : 0; }();
+    return v;
+}
+static bool tn_narrow(int N, int Ktot) { return N <= 64 && Ktot >= 192; }
+static TnShape tn_shape(int N, int Ktot, int dtype, int out_mode) {
+    if (out_mode == 0 && tn_narrow(N, Ktot)) return {64, 192, 4};
+    if (out_mode == 0 && dtype == VAMD_BF16 && tn_wide_mode()) {
+        if (N >= 128 && Ktot % 256 == 0 && Ktot >= 512) return {128, 256, 8};
+        if (N % 256 == 0 && Ktot % 128 == 0 && Ktot >= 512 && tn_wide_mode() >= 2) return {256, 128, 8};
+    }
+    return {128, 128, 4};
+}
+static int tn_shape_tiles(const TnShape& sh, int N, int Ktot) { return ((N + sh.AN - 1) / sh.AN) * ((Ktot + sh.BF - 1) / sh.BF); }
+// Pixel slices of the weight gradient: two workgroups (of four waves) per CU in all, or one of eight -- each slice runs long
+// and the partial buffer stays small; at least 8 K-steps per slice, every slice non-empty.
+static int tn_slice_cap(const TnShape& sh) {
     static const int v = [] { const char* e = getenv("VAMD_TN_BLOCKS"); return e ? atoi(e) : 0; }();
-    // 512 for every filter: in the step it equals a cap of 1024 for many-tile filters at 64 images (19.49 / 19.51 ms)
-    // and is ahead at 16 (8.06 -> 7.96 ms: fewer slices to write and add); 256 and 768+ lose 4-15 %
-    (void)tiles;
+    static const int v8 = [] { const char* e = getenv("VAMD_TN_WIDE_BLOCKS"); return e ? atoi(e) : 0; }();
+    // 512 for every filter on the four-wave shapes: in the step it equals a cap of 1024 for many-tile filters at 64 images
+    // (19.49 / 19.51 ms) and is ahead at 16 (8.06 -> 7.96 ms: fewer slices to write and add); 256 and 768+ lose 4-15 %
+    if (sh.NW == 8) return v8 > 0 ? v8 : 256;
     return v > 0 ? v : 512;
 }
-static void tn_split(int tiles, int total_steps, int* slices_out, int* steps_per_out) {
-    int slices = tn_slice_cap(tiles) / tiles;
+static void tn_split(const TnShape& sh, int tiles, int total_steps, int* slices_out, int* steps_per_out) {
+    int slices = tn_slice_cap(sh) / tiles;
     const int max_slices = (total_steps + 7) / 8;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
@@ -2474,15 +2529,11 @@ static void tn_split(int tiles, int total_steps, int* slices_out, int* steps_per
     *slices_out = (total_steps + steps_per - 1) / steps_per;
     *steps_per_out = steps_per;
 }
-// tile shape the weight-gradient launcher picks: narrow outputs (Cout <= 64) take a 64 x 192 tile,
-// which wastes no MFMA rows and divides 9 * Cin
-static bool tn_narrow(int N, int Ktot) { return N <= 64 && Ktot >= 192; }
 static int tn_wgrad_slices(const ConvGeom& g, int dtype) {
     const int Ktot = g.k * g.k * g.Cin, KP = dtype == VAMD_BF16 ? 64 : 32;
-    const bool narrow = tn_narrow(g.Cout, Ktot);
-    const int AN = narrow ? 64 : 128, BF = narrow ? 192 : 128;
+    const TnShape sh = tn_shape(g.Cout, Ktot, dtype, 0);
     int slices, steps_per;
-    tn_split(((g.Cout + AN - 1) / AN) * ((Ktot + BF - 1) / BF), (int)((g.M + KP - 1) / KP), &slices, &steps_per);
+    tn_split(sh, tn_shape_tiles(sh, g.Cout, Ktot), (int)((g.M + KP - 1) / KP), &slices, &steps_per);
     return slices;
 }
 
@@ -2554,7 +2605,12 @@ wgrad_reduce_kernel(const float* __restrict__ parts, const float* __restrict__ b
     o[0] = r4.x; o[k * k] = r4.y; o[2 * k * k] = r4.z; o[3 * k * k] = r4.w;
 }
 
-template <typename T, int AN, int BF>
+static int tn_pipe_mode() {
+    static const int v = [] { const char* e = getenv("VAMD_TN_PIPE"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+template <typename T, int AN, int BF, int NW>
 static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
                            int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, float* dbias,
                            int bias_mode, hipStream_t st) {
@@ -2562,18 +2618,24 @@ static int launch_tn_shape(const Gather& gp, const T* dy, const T* x, int N, int
     constexpr int LDS = 2 * KP * (AN + BF) * (int)sizeof(T);
     static bool configured = false;
     if (!configured) {
-        int rc = set_lds_limit(conv_tn_mfma_kernel<T, AN, BF>, LDS, "conv_tn_mfma");
+        int rc = set_lds_limit(conv_tn_mfma_kernel<T, AN, BF, NW, false>, LDS, "conv_tn_mfma");
+        if (!rc && sizeof(T) == 2) rc = set_lds_limit(conv_tn_mfma_kernel<T, AN, BF, NW, true>, LDS, "conv_tn_mfma");
         if (rc) return rc;
         configured = true;
     }
+    const TnShape sh{AN, BF, NW};
     const int n_tiles = (N + AN - 1) / AN, f_tiles = (gp.Ktot + BF - 1) / BF;
     const int total_steps = (gp.M + KP - 1) / KP;
     int slices = 1, steps_per = total_steps;
-    if (out_mode == 0) tn_split(n_tiles * f_tiles, total_steps, &slices, &steps_per);
+    if (out_mode == 0) tn_split(sh, n_tiles * f_tiles, total_steps, &slices, &steps_per);
     dim3 grid(n_tiles * f_tiles * slices, 1, batch);
     TimedLaunch timed(TIMED_TN, take_flops(2.0 * gp.M * N * gp.Ktot * batch), 2.0 * gp.M * N * gp.Ktot * batch, st);
-    hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF>), grid, dim3(256), LDS, st, gp, dy, x, N, lda, ldc, dw, n_tiles,
-                       f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode);
+    if (sizeof(T) == 2 && tn_pipe_mode())
+        hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF, NW, true>), grid, dim3(64 * NW), LDS, st, gp, dy, x, N, lda, ldc, dw,
+                           n_tiles, f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode);
+    else
+        hipLaunchKernelGGL((conv_tn_mfma_kernel<T, AN, BF, NW, false>), grid, dim3(64 * NW), LDS, st, gp, dy, x, N, lda, ldc, dw,
+                           n_tiles, f_tiles, steps_per, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode);
     VAMD_LAUNCH_OK("conv_tn_mfma");
     return 0;
 }
@@ -2582,9 +2644,16 @@ template <typename T>
 static int launch_tn(const Gather& gp, const T* dy, const T* x, int N, int lda, int ldc, float* dw, int batch,
                      int64_t sA, int64_t sB, int64_t sC, int out_mode, void* yout, float alpha, float* dbias,
                      int bias_mode, hipStream_t st) {
-    if (out_mode == 0 && tn_narrow(N, gp.Ktot))
-        return launch_tn_shape<T, 64, 192>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode, st);
-    return launch_tn_shape<T, 128, 128>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode, st);
+    const TnShape sh = tn_shape(N, gp.Ktot, sizeof(T) == 2 ? VAMD_BF16 : VAMD_F32, out_mode);
+    if (sh.AN == 64)
+        return launch_tn_shape<T, 64, 192, 4>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode, st);
+    if constexpr (sizeof(T) == 2) {
+        if (sh.NW == 8 && sh.BF == 256)
+            return launch_tn_shape<T, 128, 256, 8>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode, st);
+        if (sh.NW == 8)
+            return launch_tn_shape<T, 256, 128, 8>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode, st);
+    }
+    return launch_tn_shape<T, 128, 128, 4>(gp, dy, x, N, lda, ldc, dw, batch, sA, sB, sC, out_mode, yout, alpha, dbias, bias_mode, st);
 }
 
 size_t conv_wgrad_mfma_workspace(const ConvGeom& g, int dtype) {
@@ -2626,10 +2695,9 @@ int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x,
 // gathered dY columns of the four central taps, which cover every dY pixel exactly once.
 static int up4_slices(const ConvGeom& g, int dtype) {
     const int F = 16 * g.Cout, KP = dtype == VAMD_BF16 ? 64 : 32;
-    const bool narrow = tn_narrow(g.Cin, F);
-    const int AN = narrow ? 64 : 128, BF = narrow ? 192 : 128;
+    const TnShape sh = tn_shape(g.Cin, F, dtype, 0);
     int slices, steps_per;
-    tn_split(((g.Cin + AN - 1) / AN) * ((F + BF - 1) / BF), (int)(((int64_t)g.B * g.H * g.W + KP - 1) / KP), &slices, &steps_per);
+    tn_split(sh, tn_shape_tiles(sh, g.Cin, F), (int)(((int64_t)g.B * g.H * g.W + KP - 1) / KP), &slices, &steps_per);
     return slices;
 }
 
