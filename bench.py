@@ -83,6 +83,62 @@ def cpu_baseline(seconds_budget=22.0):
                       f"sampling 4 images x 10 steps took {samp:.1f} s"}
 
 
+def cpu_baseline_latent(kind, seconds_budget=16.0):
+    """Oracle on the host for the two latent-diffusion presets, fp32: the first stage's training step (224 x 224, batch 4,
+    Adam with L2 decay), or the latent UNet's training step on the first stage's encoder output (8 images per step: encoder
+    forward without gradient, then loss, gradients and AdamW of the latent UNet).  Steps until the budget is used."""
+    from oracle import ldm as L
+    from oracle import restatement as R
+    from oracle import vqunet as V
+    import vision_amd
+    from vision_amd.presets import get_preset
+    fs_cfg = get_preset("vqvaeunet")["model_config"]
+    torch.manual_seed(fs_cfg["manual_seed"])
+    fs = {k: v.clone() for k, v in vision_amd.get_model("vqvaeunet", fs_cfg).state_dict().items()}     # host tensors: no engine yet
+    g = torch.Generator().manual_seed(0)
+    P = fs_cfg["patch_size"]
+    if kind == "vqvaeunet":
+        B = 4
+        x = torch.rand((B, 3, P, P), generator=g)
+        params = {k: fs[k] for k in fs if V.is_param(k)}
+        m = {k: torch.zeros_like(v) for k, v in params.items()}
+        v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            grads = V.loss_and_grads(fs, fs_cfg, x)[-1]
+            V.adam_l2_step(params, grads, m, v2, steps + 1, fs_cfg["learning_rate"], fs_cfg["weight_decay"])
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > seconds_budget or steps >= 20:
+                break
+        what = f"butterfly_vqvaeunet first stage, batch {B}, fp32, {steps} training steps ({el:.1f} s) on the host CPU"
+    else:
+        B = 8
+        cfg = get_preset("ldm")["model_config"]
+        torch.manual_seed(cfg["manual_seed"])
+        sd = {k: v.clone() for k, v in vision_amd.get_model("ldm", cfg).state_dict().items()}
+        names = [k for k in sd if L.is_param(k)]
+        m = {k: torch.zeros_like(sd[k]) for k in names}
+        v2 = {k: torch.zeros_like(sd[k]) for k in names}
+        x = torch.rand((B, 3, P, P), generator=g)
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            with torch.no_grad():
+                z, _ = V.encode(fs, fs_cfg, x, False)
+            eps = torch.randn(z.shape, generator=g)
+            t = torch.rand((B, 1, 1, 1), generator=g)
+            loss, grads = L.loss_and_grads(sd, cfg, z, eps, t)
+            L.p_loss(sd, cfg, z, eps, t, True)          # the statistics update of the step
+            R.adamw_step({k: sd[k] for k in names}, grads, m, v2, steps + 1, cfg["learning_rate"], cfg["weight_decay"])
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > seconds_budget or steps >= 20:
+                break
+        what = (f"butterfly_ldm latent UNet on the butterfly_vqvaeunet encoder output, batch {B}, fp32, {steps} training steps "
+                f"({el:.1f} s) on the host CPU")
+    return {"value": round(steps * B / el, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "sample": what}
+
+
 TRAFFIC_CSV = "r2_pmc_tcc_traffic.csv"
 
 
@@ -304,7 +360,7 @@ def main():
             "roofline": roof, "sampling": sampling, **extra,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline() if kind == "ddpm" else cpu_baseline_latent(kind)
         print(json.dumps(out), flush=True)
     if grouped:
         dist.barrier()

@@ -92,29 +92,35 @@ def vq_block(weight, latents, beta=BETA):
     return q.permute(0, 3, 1, 2).contiguous(), vq_loss, idx
 
 
+def _run(sd, pfx, m, h, training, taps):
+    if m[0] == "res":
+        h = resnet_block(sd, pfx, h, training)
+    elif m[0] == "attn":
+        h = attn_block(sd, pfx, h, training)
+    elif m[0] == "down":
+        h = down_block(sd, pfx, h)
+    else:
+        h = up_block(sd, pfx, h)
+    if taps is not None:
+        taps[pfx] = h
+    return h
+
+
+def encode(sd, cfg, x, training=False, taps=None):
+    """reference models/vqvaeunet.py:215-222: (encoder output, every encoder module's output)."""
+    h = x
+    skip = []
+    for j, m in enumerate(build_plan(cfg)["down"]):
+        h = _run(sd, f"Downsampling.{j}", m, h, training, taps)
+        skip.append(h)
+    return h, skip
+
+
 def forward(sd, cfg, x, training=False, taps=None):
     """reference models/vqvaeunet.py:205-233: (x_rec, vq_loss, codes).  `taps`, if a dict, receives every module
     output by prefix, plus 'latents' and 'quantized'."""
     plan = build_plan(cfg)
-
-    def run(pfx, m, h):
-        if m[0] == "res":
-            h = resnet_block(sd, pfx, h, training)
-        elif m[0] == "attn":
-            h = attn_block(sd, pfx, h, training)
-        elif m[0] == "down":
-            h = down_block(sd, pfx, h)
-        else:
-            h = up_block(sd, pfx, h)
-        if taps is not None:
-            taps[pfx] = h
-        return h
-
-    h = x
-    skip = []
-    for j, m in enumerate(plan["down"]):
-        h = run(f"Downsampling.{j}", m, h)
-        skip.append(h)
+    h, skip = encode(sd, cfg, x, training, taps)
     q, vq_loss, idx = vq_block(sd["vq_layer.embedding.weight"], h)
     if taps is not None:
         taps["latents"], taps["quantized"] = h, q
@@ -124,7 +130,7 @@ def forward(sd, cfg, x, training=False, taps=None):
     for j, m in enumerate(plan["up"]):
         if j < len(skip):
             h = h + skip[j]                    # `h += skip[index]`, models/vqvaeunet.py:229-230
-        h = run(f"Upsampling.{j}", m, h)
+        h = _run(sd, f"Upsampling.{j}", m, h, training, taps)
     if n_up < len(skip):
         h = h + skip[n_up]
     h = torch.sigmoid(channel_linear(sd, f"Upsampling.{n_up}.0", h))
