@@ -410,7 +410,8 @@ int vamd_vq_forward(const float* z, const float* codebook, int64_t M, int D, int
 /* Gradients of the two outputs of vamd_vq_forward as autograd defines them for vqvaeunet.py:138-144:
  * dz = g_out + g_loss * beta * 2 (z - e[index]) / (M D); dcodebook[k] = g_loss * 2 / (M D) * sum over the rows with
  * index k of (e[k] - z).  g_out (layout of z) and g_loss (one device float) may be NULL (= zero); dz or dcodebook
- * may be NULL (not wanted).  D <= 1024.  Rows of one code are added in ascending order: bit-reproducible. */
+ * may be NULL (not wanted).  D <= 1024.  Rows of one code are added in a fixed order
+ * (eight interleaved partial sums per 256-row chunk, combined pairwise): bit-reproducible. */
 int vamd_vq_backward(const float* z, const float* codebook, const int64_t* indices, const float* g_out,
                      const float* g_loss, int64_t M, int D, int K, int HW, int nchw, float beta, float* dz,
                      float* dcodebook, void* stream);

@@ -22,7 +22,7 @@
 //                       (vqvaeunet.py:138-141; the two mse terms have equal values in the forward pass).
 //   vq_bwd_latents_kernel / vq_bwd_codebook_kernel   gradients of the commitment term and the straight-through
 //                       path w.r.t. the latents, and of the embedding term w.r.t. the codebook (rows of one code
-//                       are added in ascending row order by one workgroup: bit-reproducible).
+//                       are added in a fixed order by one workgroup, eight interleaved partial sums: bit-reproducible).
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -183,7 +183,7 @@ vq_bwd_latents_kernel(const float* __restrict__ z, const float* __restrict__ E, 
     }
 }
 
-// dE[k] = g_loss * 2 / (M D) * sum over the rows that chose code k of (e[k] - z[m]), rows in ascending order
+// dE[k] = g_loss * 2 / (M D) * sum over the rows that chose code k of (e[k] - z[m]), in a fixed order
 __global__ void __launch_bounds__(256)
 vq_bwd_codebook_kernel(const float* __restrict__ z, const float* __restrict__ E, const int64_t* __restrict__ indices,
                        const float* __restrict__ g_loss, int64_t M, int D, VqLayout lay, float scale,
@@ -192,11 +192,28 @@ vq_bwd_codebook_kernel(const float* __restrict__ z, const float* __restrict__ E,
     __shared__ int nrows;
     const int k = blockIdx.x, tid = threadIdx.x;
     constexpr int DMAX = 4;                                 // features per thread: D <= 1024
-    float acc[DMAX], ek[DMAX];
+    // a popular code may own most of the rows (all of them while the codebook is still near zero): eight rows are in
+    // flight per thread, row r of a chunk adds into accumulator r % 8, and the eight are summed pairwise at the end --
+    // a fixed order, so the result is reproducible run to run
+    constexpr int RU = 8;
+    float acc[RU][DMAX], ek[DMAX];
 #pragma unroll
     for (int j = 0; j < DMAX; ++j) {
-        acc[j] = 0.f;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) acc[u][j] = 0.f;
         ek[j] = tid + 256 * j < D ? E[(int64_t)k * D + tid + 256 * j] : 0.f;
+    }
+    // most codes are chosen by no row (M rows, K codes, M <= K in the shipped configuration): one pass of independent
+    // loads by all threads decides that, and such a workgroup is done after writing zeros
+    {
+        int any = 0;
+        for (int64_t m = tid; m < M; m += 256) any |= indices[m] == k ? 1 : 0;
+        if (!__syncthreads_or(any)) {
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j)
+                if (tid + 256 * j < D) dE[(int64_t)k * D + tid + 256 * j] = 0.f;
+            return;
+        }
     }
     for (int64_t m0 = 0; m0 < M; m0 += 256) {
         // rows of this chunk that chose code k, compacted in ascending order by the first wave
@@ -215,18 +232,29 @@ vq_bwd_codebook_kernel(const float* __restrict__ z, const float* __restrict__ E,
         }
         __syncthreads();
         const int n = nrows;
-        for (int r = 0; r < n; ++r) {
-            const int64_t m = m0 + rows[r];
+        for (int r = 0; r < n; r += RU) {
+            float zv[RU][DMAX];
 #pragma unroll
-            for (int j = 0; j < DMAX; ++j)
-                if (tid + 256 * j < D) acc[j] += ek[j] - z[lay.at(m, tid + 256 * j)];
+            for (int u = 0; u < RU; ++u) {
+                const int64_t m = m0 + rows[r + u < n ? r + u : r];
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j) zv[u][j] = tid + 256 * j < D ? z[lay.at(m, tid + 256 * j)] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+                if (r + u < n) {
+#pragma unroll
+                    for (int j = 0; j < DMAX; ++j) acc[u][j] += ek[j] - zv[u][j];
+                }
         }
         __syncthreads();
     }
     const float coef = g_loss ? g_loss[0] * scale : 0.f;
 #pragma unroll
     for (int j = 0; j < DMAX; ++j)
-        if (tid + 256 * j < D) dE[(int64_t)k * D + tid + 256 * j] = coef * acc[j];
+        if (tid + 256 * j < D)
+            dE[(int64_t)k * D + tid + 256 * j] =
+                coef * (((acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j])) + ((acc[4][j] + acc[5][j]) + (acc[6][j] + acc[7][j])));
 }
 
 static size_t vq_align(size_t n) { return (n + 255) & ~(size_t)255; }
