@@ -384,6 +384,11 @@ int vamd_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float 
                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                  int step, float grad_scale, void* stream);
 
+/* out[i] = a[i] (+ b[i] when b != NULL), i < n; every operand has its own dtype, the sum is taken in fp32.  The dtype
+ * changes and two-term merges around the first stage's codebook lookup: the latents and their gradient are fp32 between
+ * two halves of a network that runs in the compute dtype (reference models/vqvaeunet.py:210 and `h += skip[0]`, :230). */
+int vamd_add_cast(const void* a, int a_dtype, const void* b, int b_dtype, void* out, int out_dtype, int64_t n, void* stream);
+
 /* Head and reconstruction loss of the VQ-VAE-UNet first stage (reference models/vqvaeunet.py:206-210 nn.Sigmoid() after
  * the last channel-wise Linear, :236-240 rec_loss = F.mse_loss(x_rec, x)).
  * fwd: h [B][H][W][C] in `dtype` -> xrec [B][C][H][W] fp32 = sigmoid(h); with target (the input images, NCHW fp32) also

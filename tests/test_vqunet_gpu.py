@@ -352,3 +352,21 @@ def test_eval_mode_gradients(case):
     for k, v in sd.items():
         if "running_" in k:
             assert torch.equal(m.state_dict()[k].cpu(), v), k
+
+
+def test_add_cast_kernel():
+    from vision_amd import _lib
+    code = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+    gen = torch.Generator().manual_seed(8)
+    n = 12345
+    st = torch.cuda.current_stream().cuda_stream
+    for ta in code:
+        for tb in (None,) + tuple(code):
+            for to in code:
+                a = torch.randn(n, generator=gen).to(ta).to(DEV)
+                b = None if tb is None else torch.randn(n, generator=gen).to(tb).to(DEV)
+                out = torch.empty(n, dtype=to, device=DEV)
+                call("vamd_add_cast", a.data_ptr(), code[ta], None if b is None else b.data_ptr(), 0 if tb is None else code[tb],
+                     out.data_ptr(), code[to], n, st)
+                want = (a.float() + (b.float() if b is not None else 0.0)).to(to)
+                assert torch.equal(out, want), (ta, tb, to)

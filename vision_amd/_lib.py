@@ -138,6 +138,7 @@ SIGNATURES = {
     "vamd_resize_ksize": (_i, [_i, _i]),
     "vamd_resize_coeffs": (_i, [_i, _i, _p, _p, _i]),
     "vamd_image_resize_u8": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _i, _i, _p, _p, _p]),
+    "vamd_add_cast": (_i, [_p, _i, _p, _i, _p, _i, _l, _p]),
     "vamd_sigmoid_mse_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vamd_sigmoid_mse_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vamd_vq_workspace": (_z, [_l]),

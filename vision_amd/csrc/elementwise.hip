@@ -249,6 +249,26 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__
     }
 }
 
+// out = a (+ b), every operand in its own dtype, the sum in fp32: the dtype changes and two-term merges around the
+// codebook lookup of the first stage (fp32 latents between compute-dtype halves of the network).
+template <typename TA, typename TB, typename TO>
+__global__ void add_cast_kernel(const TA* __restrict__ a, const TB* __restrict__ b, TO* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = to_f(a[i]);
+        if (b) v += to_f(b[i]);
+        out[i] = from_f<TO>(v);
+    }
+}
+
+template <typename TA, typename TB>
+static void add_cast_out(const void* a, const void* b, void* out, int out_dtype, int64_t n, hipStream_t st) {
+    const dim3 grid(grid_for(n, 256));
+    if (out_dtype == VAMD_BF16)
+        hipLaunchKernelGGL((add_cast_kernel<TA, TB, bf16_t>), grid, dim3(256), 0, st, (const TA*)a, (const TB*)b, (bf16_t*)out, n);
+    else
+        hipLaunchKernelGGL((add_cast_kernel<TA, TB, float>), grid, dim3(256), 0, st, (const TA*)a, (const TB*)b, (float*)out, n);
+}
+
 // Layout + dtype conversion of many-channel tensors: x [batch][R][Cc] -> y [batch][Cc][R] (and an optional fp32 copy in
 // y's layout), 32 x 32 tiles through LDS (+1 pad) so that both sides move whole rows of a tile.
 template <typename TIn, typename TOut>
@@ -917,6 +937,23 @@ int vamd_nhwc_to_nchw(const void* x, float* y, int B, int C, int H, int W, int d
                            as_stream(stream), (const T*)x, y, B, C, HW);
     });
     VAMD_LAUNCH_OK("vamd_nhwc_to_nchw");
+    return 0;
+}
+
+int vamd_add_cast(const void* a, int a_dtype, const void* b, int b_dtype, void* out, int out_dtype, int64_t n, void* stream) {
+    VAMD_REQUIRE(a && out && n > 0, "vamd_add_cast: bad argument");
+    const auto ok = [](int d) { return d == VAMD_F32 || d == VAMD_BF16; };
+    VAMD_REQUIRE(ok(a_dtype) && ok(out_dtype) && (!b || ok(b_dtype)), "vamd_add_cast: dtype");
+    hipStream_t st = as_stream(stream);
+    const bool bb = b && b_dtype == VAMD_BF16;
+    if (a_dtype == VAMD_BF16) {
+        if (bb) add_cast_out<bf16_t, bf16_t>(a, b, out, out_dtype, n, st);
+        else add_cast_out<bf16_t, float>(a, b, out, out_dtype, n, st);
+    } else {
+        if (bb) add_cast_out<float, bf16_t>(a, b, out, out_dtype, n, st);
+        else add_cast_out<float, float>(a, b, out, out_dtype, n, st);
+    }
+    VAMD_LAUNCH_OK("vamd_add_cast");
     return 0;
 }
 

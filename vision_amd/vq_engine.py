@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from ._lib import call, lib
+from ._lib import BF16, F32, call, lib
 from .engine import FUSE_EVAL_NORM, Engine, _ChanAttnBlock, _Conv, _ResBlock, _Resample, _ptr, _stream
 
 
@@ -45,6 +45,19 @@ class VQUNetEngine(Engine):
 
     def _project_temb(self, temb, B):       # no time embedding in this model
         self.tproj_for, self.tproj_src = {}, None
+
+    _DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+    def _add_cast(self, a, b, dtype):
+        """a (+ b) in `dtype`, summed in fp32 (vamd_add_cast): the fp32 <-> compute-dtype steps around the lookup."""
+        a = a.contiguous()
+        out = torch.empty(a.shape, dtype=dtype, device=a.device)
+        if b is not None:
+            b = b.contiguous()
+            assert b.shape == a.shape
+        call("vamd_add_cast", _ptr(a), self._DT[a.dtype], _ptr(b), self._DT[b.dtype] if b is not None else 0, _ptr(out),
+             self._DT[dtype], a.numel(), _stream())
+        return out
 
     # ---- forward / backward on NHWC tensors
     def _begin(self, training):
@@ -102,10 +115,7 @@ class VQUNetEngine(Engine):
         last = skips[-1]
         if h.shape != last.shape:
             raise ValueError(f"latents {tuple(h.shape)} do not match the encoder output {tuple(last.shape)}")
-        if h.dtype == torch.float32 and last.dtype != torch.float32:
-            h = (h + last.float()).to(self.dtype)
-        else:
-            h = h.to(self.dtype) + last
+        h = self._add_cast(h, last, self.dtype)
         h = self._run(self.n_enc, len(self.layers), h, skips, training, tape)
         out = self.end.fwd(h)
         if tape is not None:
@@ -125,7 +135,7 @@ class VQUNetEngine(Engine):
         if self.codebook.shape[1] != D:
             raise ValueError(f"latents have {D} channels, the codebook {self.codebook.shape[1]} features")
         M = B * Hh * Wh
-        z = h.float() if h.dtype != torch.float32 else h
+        z = h if h.dtype == torch.float32 else self._add_cast(h, None, torch.float32)
         dev = h.device
         ws = torch.empty(lib.vamd_vq_workspace(M), dtype=torch.uint8, device=dev)
         idx = torch.empty(M, dtype=torch.int64, device=dev)
@@ -174,9 +184,8 @@ class VQUNetEngine(Engine):
         assert tag == "vq"
         M, D = idx.numel(), z.shape[-1]
         K = self.codebook.shape[0]
-        g32 = g_out.float() if g_out.dtype != torch.float32 else g_out
+        g32 = g_out if g_out.dtype == torch.float32 else self._add_cast(g_out, None, torch.float32)
         dz = torch.empty_like(z)
         call("vamd_vq_backward", _ptr(z), _ptr(self.codebook), _ptr(idx), _ptr(g32), _ptr(g_vq), M, D, K,
              z.shape[1] * z.shape[2], 0, self.beta, _ptr(dz), _ptr(self.g_codebook), _stream())
-        dz.add_(g32 if g_skip is g_out else g_skip.float())
-        return dz if dz.dtype == self.dtype else dz.to(self.dtype)
+        return self._add_cast(dz, g_skip, self.dtype)           # + the gradient that reached the same tensor as a skip
