@@ -303,7 +303,7 @@ def main():
                                  "launches": n, "avg_launch_ms": round(t / n, 5)}
     if layers and rank == 0:
         per_shape = {}
-        for kind, flops, e0, e1, shape in prof:
+        for _launch_kind, flops, e0, e1, shape in prof:
             f0, t0_, n0 = per_shape.get(shape, (0.0, 0.0, 0))
             per_shape[shape] = (f0 + flops, t0_ + e0.elapsed_time(e1), n0 + 1)
         for shape, (f, t, n) in sorted(per_shape.items(), key=lambda kv: -kv[1][1]):
