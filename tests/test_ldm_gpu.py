@@ -268,3 +268,23 @@ def test_run_flow_of_latent_diffusion(tmp_path, capsys):
         assert Image.open(v0 / "Samples" / f"ldm_small_Epoch_{e}.png").size == (2 * (16 + 2) + 2, 2 * (16 + 2) + 2)
     last = load_file(str(v0 / "checkpoints" / "last.safetensors"))
     assert set(last) == set(model.state_dict()) and "linear_1.linear.weight" in last and not any("vq_layer" in k for k in last)
+
+
+@pytest.mark.parametrize("preset", ["vqvaeunet", "ldm"])
+def test_bench_presets_print_one_json_line(preset):
+    """bench.py on the first-stage / latent-diffusion presets (two steps, per-layer table on): one JSON line with the
+    contract's keys, a finite positive rate and the roofline object."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--preset", preset, "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=200,
+                       env=dict(os.environ, VAMD_BENCH_LAYERS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["unit"] == "images/s" and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+    assert ("sampling" in line) and (line["sampling"] is None) == (preset == "vqvaeunet")
+    assert "layer (" in r.stderr
