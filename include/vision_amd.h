@@ -334,6 +334,18 @@ typedef struct vamd_linear_item {
 } vamd_linear_item;
 int vamd_linear_fwd_multi(const float* x, const vamd_linear_item* items, int n, int total_O, int B, int I,
                           int act_in, float slope, void* stream);
+/* The backward of vamd_linear_fwd_multi in two launches: dx[b][i] = act'(x) * sum over the entries and their outputs of
+ * dy[b][o] W[o][i] (dx may be NULL; accumulate_dx: += instead of =), and every entry's dW [O][I] and dbias [O] (may be
+ * NULL).  `items` lives in DEVICE memory, n <= 64; total_tiles = the sum over the entries of ceil(O / 16). */
+typedef struct vamd_linear_bwd_item {
+    const float* W;        /* [O][I] */
+    const float* dy;       /* [B][O] */
+    float* dW;             /* [O][I] */
+    float* dbias;          /* [O] or NULL */
+    int O, pad_;
+} vamd_linear_bwd_item;
+int vamd_linear_bwd_multi(const float* x, const vamd_linear_bwd_item* items, int n, int total_tiles, int B, int I, int act_in,
+                          float slope, float* dx, int accumulate_dx, void* stream);
 /* dx (may be NULL), dW, dbias of vamd_linear_fwd.  accumulate_dx: dx += instead of =. */
 int vamd_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW,
                     float* dbias, int B, int I, int O, int act_in, float slope,

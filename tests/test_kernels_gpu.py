@@ -933,3 +933,34 @@ def test_fused_eval_norm_refuses_what_it_cannot_do():
     z = torch.zeros(64, device=DEV)
     rc = lib.vamd_conv2d_fwd_act(C.byref(d), P(z), P(z), None, None, None, None, P(z), P(z), C.c_float(0.01), P(z), None, S())
     assert rc != 0 and b"vamd_conv2d_fwd_act" in lib.vamd_last_error()
+
+
+def test_linear_bwd_multi_matches_per_item_calls():
+    """The gradients of several linear layers over one input in two launches: dW / dbias bit-identical to the per-layer
+    calls (same summation order), dx equal to their accumulated sum up to fp32 rounding (the items are summed in table
+    order inside one thread instead of launch by launch)."""
+    from vision_amd._lib import LinearBwdItem
+    gen = torch.Generator().manual_seed(6)
+    B, I = 5, 72
+    Os = [16, 40, 130, 8]
+    x = torch.randn((B, I), generator=gen).to(DEV)
+    Ws = [torch.randn((O, I), generator=gen).to(DEV) for O in Os]
+    dys = [torch.randn((B, O), generator=gen).to(DEV) for O in Os]
+    want_dx = torch.zeros((B, I), device=DEV)
+    want = []
+    for W_, dy in zip(Ws, dys):
+        dW, db = torch.empty_like(W_), torch.empty(W_.shape[0], device=DEV)
+        call("vamd_linear_bwd", P(x), P(W_), P(dy), P(want_dx), P(dW), P(db), B, I, W_.shape[0], 1, 0.01, 1, S())
+        want.append((dW, db))
+    got = [(torch.full_like(W_, 7.0), torch.full((W_.shape[0],), 7.0, device=DEV)) for W_ in Ws]
+    items = (LinearBwdItem * len(Os))()
+    tiles = 0
+    for it, W_, dy, (dW, db), O in zip(items, Ws, dys, got, Os):
+        it.W, it.dy, it.dW, it.dbias, it.O = W_.data_ptr(), dy.data_ptr(), dW.data_ptr(), db.data_ptr(), O
+        tiles += (O + 15) // 16
+    table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(DEV)
+    dx = torch.full((B, I), 7.0, device=DEV)
+    call("vamd_linear_bwd_multi", P(x), P(table), len(Os), tiles, B, I, 1, 0.01, P(dx), 0, S())
+    for (dW, db), (wW, wb) in zip(got, want):
+        assert torch.equal(dW, wW) and torch.equal(db, wb)
+    assert relerr(dx, want_dx) < 1e-6

@@ -56,6 +56,11 @@ class LinearItem(C.Structure):
     _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("O", C.c_int32), ("first", C.c_int32)]
 
 
+class LinearBwdItem(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("dy", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p), ("O", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build the HIP extension first (python vision_amd/build_ext.py). "
@@ -124,6 +129,7 @@ SIGNATURES = {
     "vamd_timeembed": (_i, [_p, _p, _p, _i, _i, _p]),
     "vamd_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "vamd_linear_fwd_multi": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "vamd_linear_bwd_multi": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p, _i, _p]),
     "vamd_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "vamd_qsample": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vamd_schedule": (_i, [_p, _p, _p, _p, _i, _p]),

@@ -494,6 +494,86 @@ linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
     }
 }
 
+// The gradients of several linear layers over the SAME input in two launches (every ResNetBlock's linear_temb in the
+// backward pass): dx[b][i] = act'(x) * sum over items and their outputs of dy[b][o] W[o][i], and per item dW, dbias as
+// linear_bwd_dw_kernel computes them.  Items are found by a scan of the (few) entries.
+__global__ void __launch_bounds__(256)
+linear_bwd_dx_multi_kernel(const float* __restrict__ x, const vamd_linear_bwd_item* __restrict__ items, int n,
+                           float* __restrict__ dx, int B, int I, int act_in, float slope, int accumulate) {
+    __shared__ float red[16][17];
+    const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int chunks = (I + 15) / 16;
+    const int b = blockIdx.x / chunks, i = (blockIdx.x - b * chunks) * 16 + il;
+    float acc = 0.f;
+    if (i < I) {
+        for (int k = 0; k < n; ++k) {
+            const vamd_linear_bwd_item it = items[k];
+            const float* dyr = it.dy + (int64_t)b * it.O;
+#pragma unroll 4
+            for (int o = sl; o < it.O; o += 16) acc = fmaf(dyr[o], it.W[(int64_t)o * I + i], acc);
+        }
+    }
+    red[sl][il] = acc;
+    __syncthreads();
+    if (sl != 0 || i >= I) return;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][il];
+    const int64_t idx = (int64_t)b * I + i;
+    if (act_in && !(x[idx] > 0.f)) v *= slope;
+    dx[idx] = accumulate ? dx[idx] + v : v;
+}
+
+__global__ void __launch_bounds__(256)
+linear_bwd_dw_multi_kernel(const float* __restrict__ x, const vamd_linear_bwd_item* __restrict__ items, int n, int B, int I,
+                           int act_in, float slope) {
+    __shared__ float xs[64][64];
+    __shared__ float dys[64][16];
+    const int itiles = (I + 63) / 64;
+    int ot = blockIdx.x / itiles;
+    const int it_ = blockIdx.x - ot * itiles;
+    int k = 0;
+    while (k + 1 < n && ot >= (items[k].O + 15) / 16) { ot -= (items[k].O + 15) / 16; ++k; }
+    const vamd_linear_bwd_item item = items[k];
+    const int O = item.O;
+    const int o0 = ot * 16, i0 = it_ * 64;
+    if (o0 >= O) return;                                       // uniform: past the last item's tiles
+    const int il = threadIdx.x & 63, ol = threadIdx.x >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int nb = B - b0 < 64 ? B - b0 : 64;
+        for (int idx = threadIdx.x; idx < nb * 64; idx += 256) {
+            const int b = idx >> 6, i = idx & 63;
+            float v = i0 + i < I ? x[(int64_t)(b0 + b) * I + i0 + i] : 0.f;
+            if (act_in) v = leaky(v, slope);
+            xs[b][i] = v;
+        }
+        for (int idx = threadIdx.x; idx < nb * 16; idx += 256) {
+            const int b = idx >> 4, o = idx & 15;
+            dys[b][o] = o0 + o < O ? item.dy[(int64_t)(b0 + b) * O + o0 + o] : 0.f;
+        }
+        __syncthreads();
+        for (int b = 0; b < nb; ++b) {
+            const float v = xs[b][il];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g = dys[b][ol * 4 + q];
+                acc[q] = fmaf(g, v, acc[q]);
+                accb[q] += g;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = o0 + ol * 4 + q, i = i0 + il;
+        if (o < O && i < I) {
+            item.dW[(int64_t)o * I + i] = acc[q];
+            if (i == 0 && item.dbias) item.dbias[o] = accb[q];
+        }
+    }
+}
+
 // L2 false: torch.optim.AdamW (decoupled decay p *= 1 - lr wd); true: torch.optim.Adam with weight_decay (g += wd p)
 template <bool L2>
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -1083,6 +1163,18 @@ int vamd_linear_bwd(const float* x, const float* W, const float* dy, float* dx, 
     hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(((O + 15) / 16) * ((I + 63) / 64)), dim3(256), 0,
                        as_stream(stream), x, dy, dW, dbias, B, I, O, act_in, slope);
     VAMD_LAUNCH_OK("vamd_linear_bwd");
+    return 0;
+}
+
+int vamd_linear_bwd_multi(const float* x, const vamd_linear_bwd_item* items, int n, int total_tiles, int B, int I, int act_in,
+                          float slope, float* dx, int accumulate_dx, void* stream) {
+    VAMD_REQUIRE(x && items && n > 0 && n <= 64 && total_tiles > 0 && B > 0 && I > 0, "vamd_linear_bwd_multi: bad argument");
+    if (dx)
+        hipLaunchKernelGGL(linear_bwd_dx_multi_kernel, dim3(B * ((I + 15) / 16)), dim3(256), 0, as_stream(stream), x, items, n, dx,
+                           B, I, act_in, slope, accumulate_dx);
+    hipLaunchKernelGGL(linear_bwd_dw_multi_kernel, dim3(total_tiles * ((I + 63) / 64)), dim3(256), 0, as_stream(stream), x, items,
+                       n, B, I, act_in, slope);
+    VAMD_LAUNCH_OK("vamd_linear_bwd_multi");
     return 0;
 }
 

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, LinearItem, RepackItem, call, lib
+from ._lib import ConvDesc, LinearBwdItem, LinearItem, RepackItem, call, lib
 from .plan import LayerSpec, UNetPlan
 
 LEAKY_SLOPE = 0.01          # nn.LeakyReLU() default (reference models/ddpm.py:144)
@@ -230,6 +230,8 @@ FUSE_EVAL_NORM = os.environ.get("VAMD_EVAL_FUSE", "1") != "0"
 # separate kernels and without their S x S tensors in HBM.  Opt-in: measured 10-40 % slower than the three MFMA kernels
 # at the sizes of the shipped configs (4 x 1024 x 256: 62 vs 49 us; 64 x 196 x 512: 95 vs 52 us; -0.7 % on ffhq sampling)
 FUSE_ATTENTION = os.environ.get("VAMD_ATTN_FUSE", "0") != "0"
+# backward: the gradients of every block's time-embedding projection in two launches at the end instead of two per block
+BATCH_TEMB_BWD = os.environ.get("VAMD_TEMB_BWD_MULTI", "1") != "0"
 
 
 class _Norm:
@@ -411,10 +413,16 @@ class _ResBlock:
         # d(projected temb)[b][c] = sum over pixels of dh1; conv1 bias gradient = its sum over b: both
         # come out of the BatchNorm backward's statistics pass (dh1 is affine in the summed terms)
         if self.temb is not None:
-            dtproj = torch.empty((dy.shape[0], self.spec.cout), dtype=torch.float32, device=dy.device)
+            # with a slot in the step's shared buffer the projection's own gradients wait for ONE launch over all blocks
+            # at the end of backward (Engine._temb_bwd_flush); else they are computed here
+            dtproj = e.tbwd_for.get(id(self))
+            batched = dtproj is not None
+            if not batched:
+                dtproj = torch.empty((dy.shape[0], self.spec.cout), dtype=torch.float32, device=dy.device)
             dh1 = self.bn2.bwd(da2, h1, coef2, mask, img_sums=(dtproj, self.conv1.gb), training=training,
                                mask_scale=self.mask_scale)
-            self.temb.bwd(temb, dtproj, dx=dtemb, accumulate=True)
+            if not batched:
+                self.temb.bwd(temb, dtproj, dx=dtemb, accumulate=True)
         else:
             dh1 = self.bn2.bwd(da2, h1, coef2, mask, training=training, mask_scale=self.mask_scale)
         # conv1's bias feeds a train-mode BatchNorm, whose mean subtraction cancels it: the
@@ -708,6 +716,7 @@ class Engine:
         self.profile = None               # list -> receives (kind, flops, start, end) per MFMA conv launch
         self.debug_taps = None            # dict -> receives (output, folded skip) per layer (diagnostics)
         self._tproj_cache, self.tproj_for, self.tproj_src = {}, {}, None
+        self._tbwd_cache, self.tbwd_for = {}, {}
 
     def _init_layers(self, plan):
         tf = plan.time_features
@@ -828,6 +837,41 @@ class Engine:
         self.tproj_for = {id(l): v for l, v in zip(blocks, views)}
         self.tproj_src = temb
 
+    def _temb_bwd_setup(self, B):
+        """Slots [B][cout] for every ResNetBlock's gradient of its projected time embedding, in one buffer kept per
+        batch size, and the device table of vamd_linear_bwd_multi over them."""
+        blocks = [l for l in self.layers if isinstance(l, _ResBlock) and l.temb is not None]
+        self.tbwd_for = {}
+        # with a live gradient exchange a layer's gradients must be final when its backward returns (its bucket may be
+        # reduced right away), so the projections' gradients stay with their blocks
+        exchanging = self.reducer is not None and getattr(self.reducer, "_on", True)
+        if not BATCH_TEMB_BWD or exchanging or len(blocks) < 2 or len(blocks) > 64:
+            return None
+        ent = self._tbwd_cache.get(B)
+        if ent is None:
+            total = sum(l.spec.cout for l in blocks)
+            buf = torch.empty(B * total, dtype=torch.float32, device=self.device)
+            items = (LinearBwdItem * len(blocks))()
+            views, first, tiles = [], 0, 0
+            for it, l in zip(items, blocks):
+                v = buf[B * first:B * (first + l.spec.cout)].view(B, l.spec.cout)
+                it.W, it.dy, it.dW, it.dbias, it.O = (l.temb.w.data_ptr(), v.data_ptr(), l.temb.gw.data_ptr(),
+                                                      l.temb.gb.data_ptr(), l.spec.cout)
+                views.append(v)
+                first += l.spec.cout
+                tiles += (l.spec.cout + 15) // 16
+            table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+            ent = (buf, table, views, tiles, len(blocks), blocks[0].temb.cin)
+            self._tbwd_cache = {B: ent}
+        self.tbwd_for = {id(l): v for l, v in zip(blocks, ent[2])}
+        return ent
+
+    def _temb_bwd_flush(self, ent, temb, dtemb):
+        buf, table, views, tiles, n, cin = ent
+        call("vamd_linear_bwd_multi", _ptr(temb), _ptr(table), n, tiles, temb.shape[0], cin, 1, LEAKY_SLOPE, _ptr(dtemb), 0,
+             _stream())
+        self.tbwd_for = {}
+
     def draw_dropout(self, shape, p):
         """0/1 keep mask in the compute dtype, one launch; the kernels apply 1/(1-p) in fp32."""
         return torch.empty(shape, dtype=self.dtype, device=self.device).bernoulli_(1.0 - p, generator=self.drop_generator)
@@ -895,6 +939,7 @@ class Engine:
         n_up = len(self.layers) - nd - nm
         B = dout.shape[0]
         dtemb = torch.zeros((B, self.plan.time_features), dtype=torch.float32, device=dout.device)
+        tbwd = self._temb_bwd_setup(B)
         dskip: Dict[int, torch.Tensor] = {}
         for i in range(len(self.layers) - 1, -1, -1):
             layer, saved = tape.pop()
@@ -914,6 +959,8 @@ class Engine:
                 red.layer_done(self._lows[layer.spec.prefix])
         tag, (emb, t1, temb) = tape.pop()
         assert tag == "temb"
+        if tbwd is not None:
+            self._temb_bwd_flush(tbwd, temb, dtemb)
         dt1 = torch.empty_like(t1)
         self.lin2.bwd(t1, dtemb, dx=dt1)
         self.lin1.bwd(emb, dt1, dx=None)
