@@ -402,7 +402,8 @@ class _ResBlock:
     def bwd(self, saved, dy, extra, dtemb, need_dx=True):
         x, a1, coef1, h1, a2, coef2, mask, temb, training = saved
         e = self.eng
-        # conv2 and shortcut share dy; their bias gradients are the same column sums of dy
+        # conv2 and shortcut share dy; their bias gradients are the same column sums of dy (copied: letting the shortcut's
+        # weight-gradient launch form them again costs more than the copy launch, 19.29 vs 19.17 ms on the 224 x 224 step)
         self.conv2.wgrad(dy, a2)
         da2 = self.conv2.dgrad(dy, a2.shape)
         dxs = dy
