@@ -223,7 +223,11 @@ int vamd_gn_finalize(const float* partial, int nchunk, int B, int C, int groups,
  * outputs are [B][C] fp32, bit-identical to the two-call form.  The built-in buffer holds
  * VAMD_GN_NOALLOC_SCRATCH_BYTES per GPU (kept until the process ends); a shape whose partial sums
  * (B * vamd_stats_chunks(HW, B) * C * 2 floats) do not fit is rejected with VAMD_EINVAL.  Calls on one GPU
- * share that GPU's buffer: calls that overlap in time on one GPU (different streams, threads) race. */
+ * share that GPU's buffer: calls that overlap in time on one GPU (different streams, threads) race.
+ * Under HIP graph capture: the first call on a device looks the buffer's address up (hipGetSymbolAddress, under a
+ * mutex; it may load the code object and synchronise), which is not a capturable operation -- make ONE call on the
+ * device before the capture begins.  A captured graph holds the address of the one per-GPU buffer, so replays of
+ * graphs that contain this call must not overlap on a GPU either. */
 #define VAMD_GN_NOALLOC_SCRATCH_BYTES (8u << 20)
 int vamd_gn_coef_noalloc(const void* x, int B, int C, int groups, int64_t HW, const float* gamma,
                          const float* beta, float eps, float* scale, float* shift, float* mean, float* rstd,

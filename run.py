@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 import yaml
 
-from vision_amd import get_model
+from vision_amd import chose_model, get_model
 from vision_amd.trainer import DirLogger, ImageFolderDataModule, SyntheticImageFolder, Trainer, seed_everything
 from vision_amd.utils import SafetensorsCheckpoint
 
@@ -72,7 +72,7 @@ def main(argv=None):
         with open(fs_yaml, "r") as f:
             fs_cfg = yaml.safe_load(f)["model_config"]
         fs_ckpt = config["model_config"].get("first_stage_checkpoint")
-        fs_cls = get_model(fs_cfg["name"], fs_cfg).__class__
+        fs_cls = chose_model[fs_cfg["name"]]
         first = fs_cls.load_from_checkpoint(fs_ckpt, config=fs_cfg) if fs_ckpt else get_model(fs_cfg["name"], fs_cfg)
         model.set_first_stage(first)
 

@@ -217,9 +217,51 @@ def test_imagefolder_datamodule_on_disk(tmp_path):
     dm.setup()
     assert dm.num_classes == 2 and {k: len(v) for k, v in dm.splits.items()} == {"train": 16, "valid": 2, "test": 2}
     r0 = list(dm.train_dataloader(0, 2))
-    dm._epoch_seed = 0
     r1 = list(dm.train_dataloader(1, 2))
     assert len(r0) == len(r1) == 3 and [b[0].shape[0] for b in r0] == [3, 3, 2]
     x, y = r0[0]
     assert x.shape == (3, 3, 8, 8) and x.dtype == torch.float32 and 0.0 <= float(x.min()) and float(x.max()) <= 1.0
     assert y.dtype == torch.int64
+    # the order depends on the global seed and the epoch the trainer sets, not on how often a loader was asked for
+    ys = lambda it: torch.cat([b[1] for b in it]).tolist()
+    torch.manual_seed(7)
+    a0, a0_again = ys(dm.train_dataloader()), ys(dm.train_dataloader())
+    dm.epoch = 1
+    a1 = ys(dm.train_dataloader())
+    dm.epoch = 0
+    torch.manual_seed(8)
+    b0 = ys(dm.train_dataloader())
+    assert a0 == a0_again and sorted(a0) == sorted(a1) == sorted(b0)
+    paths = lambda: [p for p, _ in dm.splits["train"]]
+    assert len(paths()) == 16
+
+
+def test_shuffle_order_follows_seed_and_epoch(tmp_path):
+    from vision_amd.trainer import ImageFolderDataModule
+    dm = ImageFolderDataModule.__new__(ImageFolderDataModule)
+    dm.splits = {"train": [(f"img{i}", i) for i in range(40)]}
+    dm.batch_size, dm.device, dm.gpu_transform, dm.epoch, dm._pipeline = 40, "cpu", False, 0, None
+    dm._load = lambda path: torch.zeros(3, 2, 2)
+    order = lambda: next(iter(dm.train_dataloader()))[1].tolist()
+    torch.manual_seed(42)
+    e0 = order()
+    assert e0 == order()                         # same seed, same epoch: same order (every rank deals from it)
+    dm.epoch = 3
+    e3 = order()
+    torch.manual_seed(43)
+    dm.epoch = 0
+    other = order()
+    assert sorted(e0) == sorted(e3) == sorted(other) == list(range(40))
+    assert e0 != e3 and e0 != other
+
+
+def test_cpu_baseline_reports_its_sample():
+    """bench.py's CPU leg (the oracle on the flowers model, batch 8): the object names how many steps it timed."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline(seconds_budget=0.5)           # one step here; the default budget covers the 20 the config names
+    assert out["kind"] == "port" and out["unit"] == "images/s" and out["steps"] >= 1 and out["batch"] == 8
+    assert out["value"] > 0 and out["cores"] >= 1 and "training steps" in out["sample"]

@@ -111,13 +111,13 @@ CONV_CASES = [
 ]
 
 
-# Shapes the ping-pong kernel takes at its default thresholds with a scratch buffer: the row tiles' reduction is
-# then split between workgroups (every CU an equal share of K-tiles; tiles that straddle shares are summed from
-# partial results).  B, H, W, Cin, Cout, k, stride, up
+# Shapes with fewer row tiles than the chip has CUs: with a scratch buffer in the descriptor the kernels may split such a
+# layer's reduction between workgroups (partial products summed in a fixed order); without one they run whole tiles.
+# B, H, W, Cin, Cout, k, stride, up
 SPLIT_CASES = [
-    (4, 56, 56, 256, 256, 3, 1, 0),       # 49 tiles of 256 x 256 on 256 workgroups: every tile split 5 ways
+    (4, 56, 56, 256, 256, 3, 1, 0),       # 49 tiles of 256 x 256
     (2, 112, 112, 128, 128, 3, 1, 0),     # 49 tiles of 512 x 128
-    (8, 28, 28, 256, 512, 3, 1, 0),       # two column tiles: 25 row tiles each on 128 workgroups
+    (8, 28, 28, 256, 512, 3, 1, 0),       # two column tiles, 25 row tiles each
     (32, 14, 14, 512, 512, 3, 1, 1),      # upsampling conv: its input gradient is a 4 x 4 stride-2 conv (K = 16 * 512)
     (7, 223, 111, 128, 128, 3, 2, 0),     # stride 2, ragged last tile
 ]
@@ -137,10 +137,8 @@ WIDE_CASES = [
 def test_conv_wide_tiles(case):
     """Forward (with bias, time embedding, residual, skip and fused BatchNorm statistics) and input gradient with the
     descriptor's optional scratch buffer against fp64, and against the same calls without it (whole tiles): the
-    two differ in fp32 summation order only.  Run twice: the flags of the first launch must not satisfy the second."""
-    split = os.environ.get("VAMD_NT8_STREAMK") == "1"      # split shares are opt-in: at these sizes they cost what they save
-    if not split and case in SPLIT_CASES:
-        pytest.skip("too few tiles for the whole-tile form of the kernel; the split form needs VAMD_NT8_STREAMK=1")
+    two differ in fp32 summation order at most.  Run twice with the buffer: nothing a launch leaves in it may reach the
+    next one, and the results are bit-reproducible."""
     B, H, W, Cin, Cout, k, stride, up = case
     tdt, dt = DT["bf16"]
     gen = torch.Generator().manual_seed(sum(case))
@@ -161,7 +159,7 @@ def test_conv_wide_tiles(case):
     Ho, Wo = y64.shape[2], y64.shape[3]
     scratch = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=DEV)
     outs = {}
-    for name, sc in (("plain", None), ("split", scratch), ("split again", scratch))[:3 if split else 1]:
+    for name, sc in (("plain", None), ("split", scratch), ("split again", scratch)):
         d = ConvDesc(B, H, W, Cin, Cout, k, stride, pad, up, dt, _lib.ALGO_MFMA)
         if sc is not None:
             d.scratch, d.scratch_bytes = sc.data_ptr(), sc.numel()
@@ -196,8 +194,6 @@ def test_conv_wide_tiles(case):
             dx0 = torch.full((B, H, W, Cin), 7.0, dtype=tdt, device=DEV)
             call("vamd_conv2d_dgrad", C.byref(d), P(dyn), P(wd), None, P(dx0), P(ws), nb, S())
             assert relerr(dx0.permute(0, 3, 1, 2), gx) < TOL_OUT["bf16"], name
-    if not split:
-        return
     # same inputs, same split: bit-reproducible; against whole tiles: rounding of a different summation order
     assert torch.equal(outs["split"][0], outs["split again"][0]) and torch.equal(outs["split"][1], outs["split again"][1])
     assert relerr(outs["split"][0], outs["plain"][0].double()) < 2e-3

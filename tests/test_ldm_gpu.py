@@ -270,21 +270,33 @@ def test_run_flow_of_latent_diffusion(tmp_path, capsys):
     assert set(last) == set(model.state_dict()) and "linear_1.linear.weight" in last and not any("vq_layer" in k for k in last)
 
 
-@pytest.mark.parametrize("preset", ["vqvaeunet", "ldm"])
+@pytest.mark.parametrize("preset", ["vqvaeunet", "ldm", "flowers"])
 def test_bench_presets_print_one_json_line(preset):
-    """bench.py on the first-stage / latent-diffusion presets (two steps, per-layer table on): one JSON line with the
-    contract's keys, a finite positive rate and the roofline object."""
+    """bench.py on the first-stage / latent-diffusion presets and on a small batch of the flowers DDPM (two steps, per-layer
+    table on): one JSON line with the contract's keys, a finite positive rate, the roofline object with the fields it is
+    computed from, and the exchange object."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    extra = ["--batch", "2"] if preset == "flowers" else []
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--preset", preset, "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=200,
+                        "--no-cpu-baseline"] + extra, cwd=root, capture_output=True, text=True, timeout=200,
                        env=dict(os.environ, VAMD_BENCH_LAYERS="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["unit"] == "images/s" and line["value"] > 0 and line["n_gpus"] == 1 and line["steps"] == 2
-    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0 and 0 < roof["frac"] < 1
+    assert roof["launches"] > 0 and roof["avg_launch_ms"] > 0 and roof["flops_per_launch"] > 0
+    # achieved = FLOPs per launch / average launch time, frac = achieved / peak: the line must be consistent with itself
+    ach = roof["flops_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e12
+    assert abs(ach - roof["achieved"]) <= 0.02 * roof["achieved"] + 0.1
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert 0 < roof["executed_frac"] <= roof["frac"] + 1e-4
+    assert line["wgrad_kernel"]["launches"] > 0 and line["wgrad_kernel"]["achieved_tflops"] > 0
+    assert line["host_issue_ms_per_step"] > 0 and line["mfma_conv_ms_per_step"] > 0
+    assert line["exchange"]["ranks"] == 1 and not line["exchange"]["live"]
     assert ("sampling" in line) and (line["sampling"] is None) == (preset == "vqvaeunet")
     assert "layer (" in r.stderr

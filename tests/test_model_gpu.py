@@ -23,6 +23,8 @@ the softmax attention) must only stay negligible.
 Other tolerances: forward 1e-4 / 2e-2 vs the golden output, sampler 1e-3 / 5e-2 of max|ref| per
 pixel (fp32 / bf16).
 """
+import os
+
 import pytest
 import torch
 
@@ -47,6 +49,11 @@ TOL = {
     torch.float32: dict(fwd=1e-4, loss=1e-5, grad=5e-4, bn=1e-4, state=5e-4, gen=1e-3),
     torch.bfloat16: dict(fwd=2e-2, loss=1e-2, grad=6e-2, bn=1e-2, state=2e-2, gen=5e-2),
 }
+
+
+# three AdamW steps, fp32 compute, update of every parameter tensor against the reference's: over all elements, over the
+# elements whose update has the reference's direction, and the share of elements that moved the other way
+ADAM_REL_ALL, ADAM_REL_KEPT, ADAM_FLIPPED = 0.4, 0.4, 0.2
 
 
 def rel(a, b):
@@ -230,7 +237,14 @@ def test_three_adamw_steps_then_eval_and_sample(golden, mode):
                 # frequency (2 pi 1000) turns that into ~1e-4 on the prediction, and one L1 sign flip among the 3072
                 # outputs moves the gradients it reaches by ~2 / sqrt(3072) (seen: 0.31 on one BatchNorm weight of
                 # t0_pool, whose forward-path gradients agree with fp64 to 5e-6)
-                assert rel(sd[k].cpu() - p0[k], v - p0[k]) < 0.4, k
+                du, dv = sd[k].cpu() - p0[k], v - p0[k]
+                flipped = (du * dv) < 0            # elements that moved the other way: an L1 / Adam sign flip
+                r_all, r_kept = rel(du, dv), rel(du[~flipped], dv[~flipped])
+                if os.environ.get("VAMD_TEST_REPORT"):
+                    with open(os.environ["VAMD_TEST_REPORT"], "a") as f:
+                        f.write(f"{mode} {k} numel {v.numel()} flipped {int(flipped.sum())} rel_all {r_all:.4f} rel_kept {r_kept:.4f}\n")
+                assert r_all < ADAM_REL_ALL and r_kept < ADAM_REL_KEPT and flipped.float().mean().item() <= ADAM_FLIPPED, \
+                    (k, r_all, r_kept, int(flipped.sum()), v.numel())
 
     # validation loss + sampler from the REFERENCE's trained state (isolates them from step drift)
     m2 = make_model(cfg, sub(g, "state3"), mode).eval()

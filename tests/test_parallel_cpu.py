@@ -173,3 +173,43 @@ def test_grad_reducer_bucket_layout():
     assert r.buckets[-1] == (0, 50) and r.buckets[-2] == (50, 100)
     r = GradReducer(flat, bounds, bucket_bytes=1200, head_bytes=20)       # no boundary within the head: unchanged
     assert r.buckets[-1] == (0, 100)
+
+
+def _timing_worker(rank, world):
+    flat = torch.full((1000,), float(rank + 1))
+    red = GradReducer(flat, [0, 250, 500, 750], bucket_bytes=1000)
+    red.timing = []
+    for _ in range(3):
+        flat.fill_(float(rank + 1))
+        red.begin()
+        red.finish()
+        red.wait()
+        assert torch.allclose(flat, torch.full((1000,), 1.5))
+    ms = red.exposed_ms()
+    assert len(ms) == 3 and all(0.0 <= v < 10_000.0 for v in ms)          # one exposed-wait figure per step
+    red.timing = None
+    red.begin(); red.finish(); red.wait()
+    assert red.exposed_ms() == []
+
+
+def test_grad_reducer_reports_exposed_wait_per_step():
+    _spawn(_timing_worker, 2)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus 8` where fewer GPUs are visible ends with an error and prints no result line: a one-GPU line under
+    that command would be read as the 8-GPU result."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("8 GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VAMD_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "{" not in r.stdout and "8" in r.stderr and "visible" in r.stderr
+    # an outer launcher whose world size disagrees with --gpus is refused as well
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       cwd=root, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "{" not in r.stdout and "WORLD_SIZE=2" in r.stderr

@@ -159,6 +159,9 @@ def test_rccl_path_with_one_rank_group():
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0
     assert 0.0 < res["final_loss"] < 10.0
+    ex = res["exchange"]          # the communicator counted its own ranks; the exchange ran and was timed on the device
+    assert ex["backend"] == "nccl" and ex["rccl_ranks"] == 1 and ex["live"] and len(ex["buckets_bytes"]) >= 4
+    assert ex["exposed_allreduce_ms_per_step"] is not None and 0.0 <= ex["exposed_allreduce_ms_per_step"] < 50.0
 
 
 def test_run_py_with_two_ranks_fits_and_tests_on_rank0(tmp_path):
@@ -191,3 +194,32 @@ def test_run_py_with_two_ranks_fits_and_tests_on_rank0(tmp_path):
     rows = [json.loads(l) for l in open(v0 / "metrics.jsonl")]
     assert len(rows) == 1 and rows[0]["step"] == 10         # 80 training images / 2 ranks / batch 4
     assert (v0 / "checkpoints" / "last.safetensors").exists()
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself (as a child,
+    before it touches the GPU) and relays rank 0's line, which must report the two ranks that joined, the buckets of the
+    exchange and its exposed time per step.  Two gloo ranks share this one GPU (VAMD_DIST_BACKEND=gloo); with RCCL the
+    same command needs two GPUs and must refuse to run here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+            "--no-sampling", "--preset", "flowers", "--batch", "4"]
+    out = subprocess.run(args, env=dict(base, VAMD_DIST_BACKEND="gloo", VAMD_DIST_TIMEOUT_S="90"), cwd=root,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["config"]["parallelism"] == "dp2"
+    ex = res["exchange"]
+    assert ex["ranks"] == 2 and ex["backend"] == "gloo" and ex["rccl_ranks"] is None and ex["live"]
+    assert sum(ex["buckets_bytes"]) == ex["payload_bytes_per_step"] and 99e6 < ex["payload_bytes_per_step"] < 100e6
+    assert ex["exposed_allreduce_ms_per_step"] is not None and ex["exposed_allreduce_ms_per_step"] >= 0.0
+    assert 0.0 < res["final_loss"] < 10.0
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(args, env=base, cwd=root, capture_output=True, text=True, timeout=120)
+        assert out.returncode != 0 and "{" not in out.stdout and "visible" in out.stderr

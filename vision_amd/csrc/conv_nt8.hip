@@ -21,20 +21,14 @@
 // two K-tiles after it was last read.  The K-tiles of consecutive row tiles form one stream: the ring
 // does not drain between tiles.
 //
-// Work is cut by K-tiles, not by tiles ("stream-K"): the row tiles of a column tile times their K-tiles form
-// one sequence of units, and every workgroup of the column takes an equal contiguous share of it.  A share
-// that starts inside a tile produces a partial sum for that tile first (stored to the caller's scratch
-// buffer and published with an agent-scope release + flag), then whole tiles, and, if it ends inside a
-// tile, it owns that tile: it waits for the flags of the workgroups holding the rest of the tile's K-tiles
-// (which computed them first thing), adds their partial sums in a fixed order and runs the epilogue.  With
-// every workgroup resident (one per CU) all CUs finish together whatever the tile count.  Without a
-// scratch buffer the shares are whole tiles.
+// Work is cut by whole tiles: workgroup j of a column tile takes row tiles j, j + groups, ... so that the workgroups
+// running at one time work on neighbouring tiles (their input halos and the filter meet in L2).  (A split of the
+// K-tiles of a tile between workgroups, with partial sums exchanged through flags in global memory, was measured to
+// cost what it saves and made the result depend on every workgroup of the grid being resident at once; it is gone.)
 //
 // 64-byte rows are read conflict-free by ds_read_b128 with the 16-byte chunk index XORed with
 // f(row) = (4 - (row >> 2 & 3)) & 3; the direct-to-LDS image is lane-linear, so the permutation is applied
 // to the source address of the load.
-#include <atomic>
-
 #include "conv_nt_common.h"
 
 #ifndef VAMD_NT8_ABLATE
@@ -72,7 +66,7 @@ __device__ __forceinline__ void nt8_frag_wait(bf16x8_t (&a)[4], bf16x8_t (&b)[4]
 template <int BM, int BN, bool STATS>
 __global__ void __launch_bounds__(512)
 conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, int N, int ldw, int ldc,
-                Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles, unsigned char* scratch, uint32_t epoch) {
+                Epilogue ep, void* __restrict__ yout, int m_tiles, int n_tiles) {
     using T = bf16_t;
     using Frag = bf16x8_t;
     constexpr int NPA = BM / 128, NPB = BN / 128;          // 16-byte pieces per thread and K-tile
@@ -97,17 +91,10 @@ conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restric
     const int wj = bid / n_tiles;                          // this workgroup's position among them
     const int n0 = nt * BN;
     const int nk = gp.Ktot / kNt8BK;
-    // this workgroup's share [u0, u1) of the column's m_tiles * nk units (a unit = one K-tile of one row tile)
-    auto share_start = [&](int j) -> int {
-        return (int)((int64_t)j * m_tiles * nk / groups);
-    };
-    // Whole tiles (no scratch buffer): workgroup j takes row tiles j, j + groups, ... so that the workgroups
-    // running at one time work on neighbouring tiles (their input halos and the filter meet in L2).
-    // Split shares: a contiguous run of units, tile after tile.
-    const int t_step = scratch ? 1 : groups;
-    const int u0 = scratch ? share_start(wj) : 0;
-    const int n_units = scratch ? share_start(wj + 1) - u0 : (wj < m_tiles ? (m_tiles - wj + groups - 1) / groups * nk : 0);
-    const int t_first = scratch ? u0 / nk : wj, k_first = scratch ? u0 - t_first * nk : 0;
+    // this workgroup's units (a unit = one K-tile of one row tile): row tiles wj, wj + groups, ...
+    const int t_step = groups;
+    const int n_units = wj < m_tiles ? (m_tiles - wj + groups - 1) / groups * nk : 0;
+    const int t_first = wj;
 
     // ---- staging: this thread copies physical chunk `pch` of LDS rows lrow + 128*i
     const int lrow = tid >> 2, pch = tid & 3;
@@ -133,7 +120,7 @@ conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restric
     int s_tile = t_first, s_left = n_units;                // tile being staged, units left to stage
     bool s_more = s_left > 0;
 
-    auto setup = [&](int row_tile, int k_first) {
+    auto setup = [&](int row_tile) {
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const uint32_t m = row_tile * BM + lrow + 128 * i;
@@ -154,12 +141,7 @@ conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restric
             const uint32_t m3 = ((gp.kr > 3) & row_ok & ((unsigned)(h0 + 3) < (unsigned)gp.He)) ? (cm << (3 * gp.ks)) : 0u;
             a_mask[i] = m0 | m1 | m2 | m3;
         }
-        s_k = k_first;
-        const int e = k_first * kNt8BK;                    // reduction element the share starts at
-        s_tap = e / gp.Cin;
-        s_c = e - s_tap * gp.Cin;
-        s_tr = s_tap / gp.ks;
-        s_ts = s_tap - s_tr * gp.ks;
+        s_k = 0; s_c = 0; s_tap = 0; s_tr = 0; s_ts = 0;
     };
     // loads of the staged K-tile: half 0 = the first NPA/2 pixel pieces and the filter pieces, half 1 = the rest
     auto stage_half = [&](int stage, int half) {
@@ -190,9 +172,9 @@ conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restric
             s_tile += t_step;
 #if VAMD_NT8_ABLATE == 2
             s_k = 0; s_c = 0; s_tr = 0; s_ts = 0; s_tap = 0;
-            if (s_more && ldc == -1) setup(s_tile, 0);
+            if (s_more && ldc == -1) setup(s_tile);
 #else
-            if (s_more) setup(s_tile, 0);
+            if (s_more) setup(s_tile);
 #endif
         }
     };
@@ -208,11 +190,11 @@ conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restric
     float s1[STATS ? CPL : 1], s2[STATS ? CPL : 1];
 #pragma unroll
     for (int e = 0; e < (STATS ? CPL : 1); ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    auto init_acc = [&](bool with_bias) {                  // a partial sum of a tile's tail starts from zero
+    auto init_acc = [&]() {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (ep.bias && with_bias) {
+            if (ep.bias) {
                 const int n = nb + (j >> 1) * 32 + (j & 1) * 4;
                 if (n + 4 <= N) {
                     const float4 t4 = *reinterpret_cast<const float4*>(ep.bias + n);
@@ -228,10 +210,9 @@ conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restric
     };
 
     if (!s_more) return;                                   // an empty share (never launched so)
-    int cur = t_first, c_k = k_first, c_left = n_units;    // tile / K-tile being computed, units left
-    bool seg_k0 = c_k == 0;                                // the running segment holds the tile's first K-tile
-    init_acc(seg_k0);
-    setup(s_tile, c_k);
+    int cur = t_first, c_left = n_units;                   // tile being computed, units left
+    init_acc();
+    setup(s_tile);
     // prologue: two K-tiles in flight, the first one landed
     stage_half(0, 0); stage_half(0, 1); staged();
     if (s_more) {
@@ -243,73 +224,15 @@ conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restric
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger: waves 4..7 run one barrier behind
 
-    // partial sums travel through the caller's scratch buffer: [0, 4096) one flag word per workgroup of the
-    // grid, then one slot of BM * BN floats per workgroup, 16 bytes per lane and register quad
-    uint32_t* flags = reinterpret_cast<uint32_t*>(scratch);
-    constexpr int SLOT_BYTES = BM * BN * 4;
-    // Slot accesses go through a buffer resource (slot base in scalar registers, one lane offset, the register
-    // quad's offset as a scalar operand): no per-quad 64-bit addresses for the compiler to keep alive.
-    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
-    auto slot_rsrc = [&](int j) { return make_rsrc(scratch + 4096 + (int64_t)(j * n_tiles + nt) * SLOT_BYTES); };
-    auto store_partial = [&]() {                           // this workgroup's head segment -> its slot, published
-        const __amdgpu_buffer_rsrc_t rs = slot_rsrc(wj);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc0[j][i]), rs, tid * 16, (j * 4 + i) * 8192, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc1[j][i]), rs, tid * 16, (16 + j * 4 + i) * 8192, 0);
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // one barrier: waves 4..7 run one barrier behind waves 0..3, so once a wave of the second group is past
-        // it every wave of the workgroup has drained its stores
-        __builtin_amdgcn_s_barrier();
-        if (wave_s == 4 && lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(flags + wj * n_tiles + nt, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    auto add_partials = [&](int tile) {                    // the rest of `tile`'s K-tiles, held by the next workgroups
-        const int tile_end = (tile + 1) * nk;
-        for (int j = wj + 1; j < groups && share_start(j) < tile_end; ++j) {
-            if (lane == 0) {
-                uint32_t* f = flags + j * n_tiles + nt;
-                int spins = 0;
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch && ++spins < (1 << 22))
-                    __builtin_amdgcn_s_sleep(8);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const __amdgpu_buffer_rsrc_t rs = slot_rsrc(j);
-#pragma unroll
-            for (int jj = 0; jj < NT; ++jj) {
-                u32x4_t v0[4], v1[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v0[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, (jj * 4 + i) * 8192, 0);
-                    v1[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, (16 + jj * 4 + i) * 8192, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc0[jj][i] += __builtin_bit_cast(f32x4_t, v0[i]);
-                    acc1[jj][i] += __builtin_bit_cast(f32x4_t, v1[i]);
-                }
-            }
-        }
-    };
-
     int st_r = 0, st_w = 2;                                // stage read / stage written
     Frag fa[4], fb[NT];
     while (c_left > 0) {
-        // the K-tiles of this share that belong to the tile being computed
-        const int seg = nk - c_k < c_left ? nk - c_k : c_left;
         // A wait the compiler can see (vmcnt(0), other counters untouched): without it, it takes loads of the
         // segment-end code for pending and drains vmcnt inside the K-tile loop, every K-tile.  (Stores count in
         // vmcnt in order with the loads, so the first counted wait of the loop would wait for the epilogue's
         // stores anyway; the ring is two K-tiles deep again one K-tile later.)
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        for (int k = 0; k < seg; ++k) {
+        for (int k = 0; k < nk; ++k) {
             const uint32_t sa = fa_base + st_r * STAGE;
             const uint32_t sb = fb_base + st_r * STAGE;
             // ---------------- phase 0: pixel rows 0..63
@@ -361,17 +284,12 @@ conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restric
             st_r = (st_r + 1) & 3;
             st_w = (st_w + 1) & 3;
         }
-        c_left -= seg;
-        c_k += seg;
-        // ---- end of this tile's segment (no barrier on the common path: the other group keeps its own pace)
-        if (!seg_k0) {
-            store_partial();                               // a tail of the tile: its owner adds it
-        } else
+        c_left -= nk;
+        // ---- end of the tile (no barrier: the other group keeps its own pace)
 #if VAMD_NT8_ABLATE == 1
         if (ldc == -1)                                     // never true: the epilogue stays compiled, and is skipped
 #endif
         {
-            if (c_k != nk) add_partials(cur);              // this share ends inside the tile it began: it owns it
             // the lane's 16 channels in two halves: half the residual pieces and embedding terms live at a time
             const uint32_t m_first = (uint32_t)(cur * BM + wm * 128 + frow);
             // (the second run's accumulators are tiles 2 and 3 = template offset 8; its channels start at nb + 32)
@@ -383,9 +301,7 @@ conv_nt8_kernel(Gather gp, const bf16_t* __restrict__ x, const bf16_t* __restric
                                               ep.alpha, 0, yout, N, ldc, 0, m_first + 64, nb + 24);
         }
         cur += t_step;
-        c_k = 0;
-        seg_k0 = true;
-        if (c_left > 0) init_acc(true);
+        if (c_left > 0) init_acc();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();            // both groups have passed the same number of barriers
 
@@ -439,44 +355,25 @@ static int nt8_tile(int N) {
 
 struct Nt8Plan {
     int bm, bn, m_tiles, n_tiles, groups;                  // groups: workgroups per column tile
-    bool split;                                            // shares cut by K-tiles (needs the scratch buffer)
 };
 
-static constexpr size_t nt8_scratch_bytes(int workgroups) { return 4096 + (size_t)workgroups * 256 * 256 * 4; }
-
-static Nt8Plan nt8_plan(const Gather& gp, int N, const Epilogue& ep) {
-    // Off unless asked for: measured on MI355X, exchanging a 256 KB partial tile per workgroup costs about what the
-    // uneven last round of whole tiles costs (both ~20 us per launch at these layer sizes).
-    static const int streamk = nt8_env("VAMD_NT8_STREAMK", 0);
+static Nt8Plan nt8_plan(const Gather& gp, int N) {
     Nt8Plan p;
     p.bn = nt8_tile(N);
     p.bm = p.bn == 256 ? 256 : 512;
     p.m_tiles = (gp.M + p.bm - 1) / p.bm;
     p.n_tiles = N / p.bn;
-    const int nk = gp.Ktot / kNt8BK;
-    // whole tiles: as many workgroups per column as fit the chip, row tiles spread evenly
+    // as many workgroups per column as fit the chip, row tiles spread evenly
     int rmax = 256 / p.n_tiles;
     if (rmax < 1) rmax = 1;
     const int rounds = (p.m_tiles + rmax - 1) / rmax;
     p.groups = (p.m_tiles + rounds - 1) / rounds;
-    p.split = false;
-    // shares of K-tiles: every CU gets the same number of them (at least 8 each)
-    if (streamk && ep.scratch && 256 % p.n_tiles == 0) {
-        int g = 256 / p.n_tiles;
-        const int64_t units = (int64_t)p.m_tiles * nk;
-        if (units < 8ll * g) g = (int)(units / 8 > 0 ? units / 8 : 1);
-        if (ep.scratch_bytes >= nt8_scratch_bytes(g * p.n_tiles) && (p.m_tiles % g) != 0) {
-            p.groups = g;
-            p.split = true;
-        }
-    }
     return p;
 }
 
 bool nt8_applicable(const Gather& gp, int N, int ldw, int ldc, const Epilogue& ep, int batch) {
     static const int on = nt8_env("VAMD_NT8", 1);
     static const int min_tiles = nt8_env("VAMD_NT8_MIN", 200);
-    static const int min_tiles_split = nt8_env("VAMD_NT8_MIN_SPLIT", 48);
     if (!on || batch != 1 || gp.shift || gp.ostep || gp.Cin2 > 0 || ep.out_f32 || ep.alpha != 1.0f) return false;
     if (gp.Cin % kNt8BK != 0 || gp.ldx != gp.Cin || ldc != N) return false;
     if (gp.kr * gp.ks > 16) return false;
@@ -496,16 +393,11 @@ bool nt8_applicable(const Gather& gp, int N, int ldw, int ldc, const Epilogue& e
     if (!with_terms && (ep.temb || ep.res || ep.res2 || ep.stats)) return false;
     static const int wide_k = nt8_env("VAMD_NT8_WIDE_K", 1152);
     if (nt8_tile(N) == 256 && gp.Ktot > wide_k) return false;
-    const Nt8Plan p = nt8_plan(gp, N, ep);
-    const int64_t tiles = (int64_t)p.m_tiles * p.n_tiles;
-    return tiles >= (p.split ? (min_tiles < min_tiles_split ? min_tiles : min_tiles_split) : min_tiles);
+    const Nt8Plan p = nt8_plan(gp, N);
+    return (int64_t)p.m_tiles * p.n_tiles >= min_tiles;
 }
 
-int nt8_stats_parts(const Gather& gp, int N, const Epilogue& ep) { return nt8_plan(gp, N, ep).groups; }
-
-// Flags of a launch carry its own number, so the scratch buffer never needs clearing between launches: ONE
-// counter for every launch of the process, whatever its tile shape (they share the flag words).
-static std::atomic<uint32_t> g_nt8_launch_no{0};
+int nt8_stats_parts(const Gather& gp, int N, const Epilogue& ep) { (void)ep; return nt8_plan(gp, N).groups; }
 
 template <int BM, int BN>
 static int launch_nt8_tile(const Gather& gp, const Nt8Plan& p, const bf16_t* x, const bf16_t* w, int N, int ldw, int ldc,
@@ -520,26 +412,20 @@ static int launch_nt8_tile(const Gather& gp, const Nt8Plan& p, const bf16_t* x, 
         }
         configured = true;
     }
-    uint32_t epoch = 0;
-    unsigned char* scratch = nullptr;
-    if (p.split) {
-        scratch = ep.scratch;
-        do { epoch = g_nt8_launch_no.fetch_add(1) + 1; } while (epoch == 0);
-    }
     TimedLaunch timed(TIMED_NT, flops, executed, st);
     if (ep.stats)
         hipLaunchKernelGGL((conv_nt8_kernel<BM, BN, true>), dim3(p.groups * p.n_tiles), dim3(512), LDS, st, gp, x, w, N, ldw,
-                           ldc, ep, y, p.m_tiles, p.n_tiles, scratch, epoch);
+                           ldc, ep, y, p.m_tiles, p.n_tiles);
     else
         hipLaunchKernelGGL((conv_nt8_kernel<BM, BN, false>), dim3(p.groups * p.n_tiles), dim3(512), LDS, st, gp, x, w, N, ldw,
-                           ldc, ep, y, p.m_tiles, p.n_tiles, scratch, epoch);
+                           ldc, ep, y, p.m_tiles, p.n_tiles);
     VAMD_LAUNCH_OK("conv_nt8");
     return 0;
 }
 
 int launch_nt8(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep, void* y,
                double flops, double executed, hipStream_t st) {
-    const Nt8Plan p = nt8_plan(gp, N, ep);
+    const Nt8Plan p = nt8_plan(gp, N);
     if (p.bn == 256)
         return launch_nt8_tile<256, 256>(gp, p, (const bf16_t*)x, (const bf16_t*)w, N, ldw, ldc, ep, y, flops, executed, st);
     return launch_nt8_tile<512, 128>(gp, p, (const bf16_t*)x, (const bf16_t*)w, N, ldw, ldc, ep, y, flops, executed, st);

@@ -147,7 +147,12 @@ class LatentDiffusion(DDPMModel):
 
     @torch.no_grad()
     def decode_latents(self, latents, skip=None):
-        """Codebook lookup (codes in `self.last_codes`), then the first stage's decoder; absent skips are zeros."""
+        """Codebook lookup (codes in `self.last_codes`), then the first stage's decoder; absent skips are zeros.
+        DIAGNOSTIC ONLY without `skip`: the first stage's decoder adds an encoder skip before every module (reference
+        models/vqvaeunet.py:224-233), full-resolution features included, so images decoded from all-zero skips lie outside
+        anything the first stage was trained on; the reference defines no way to decode a sampled latent.  Pass the skips
+        of a held-out batch's encoder pass (the second value of the first stage's `encode(images)`) to decode in the regime
+        the decoder knows."""
         fs = self._stage_on(latents.device)
         was = fs.training
         fs.eval()
@@ -186,7 +191,8 @@ class LatentDiffusion(DDPMModel):
 
     def sample_images(self):
         """Sampled latents, decoded through the first stage when one is attached (reference models/ldm.py:362-373 saves
-        the sampler's output as an image; latents of 256 channels are not one)."""
+        the sampler's output as an image; latents of 256 channels are not one).  The decodes use all-zero skips and are
+        diagnostic pictures of the sampled codes, not samples of a generative decoder (see decode_latents)."""
         latents = self.generate(self.grid ** 2, self.diffusion_steps)
         if self._first_stage is None:
             return latents

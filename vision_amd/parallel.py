@@ -18,6 +18,7 @@ issued asynchronously; the optimiser waits for all of them.  On a fully connecte
 a 25 MB bucket moves in ~0.2 ms, so the exchange hides behind the remaining backward kernels.
 """
 import os
+import time
 from typing import List, Optional
 
 import torch
@@ -90,10 +91,23 @@ class GradReducer:
         self._use_avg = backend == "nccl"     # ReduceOp.AVG exists for nccl/RCCL only
         # VAMD_DP_SERIAL=1: blocking collectives (no overlap with backward), for debugging
         self._serial = os.environ.get("VAMD_DP_SERIAL", "0") == "1"
+        # a list here switches on the measurement of the EXPOSED part of the exchange: per step, how long the compute
+        # stream has to wait between backward's last kernel and the landing of the last bucket (everything earlier runs
+        # beside backward).  Device events on the RCCL path; with staged (host) transport the host time of wait().
+        self.timing: Optional[list] = None
+        self._t_end = None
 
     def begin(self):
         self._next = 0
         self._pending = []
+        self._t_end = None
+
+    def exposed_ms(self):
+        """Per measured step, the milliseconds described at `timing` (call after a device synchronisation)."""
+        out = []
+        for a, b in self.timing or []:
+            out.append(a.elapsed_time(b) if b is not None else a)
+        return out
 
     def layer_done(self, low_offset: int):
         """Gradients at arena offsets >= low_offset are final: issue every bucket that is complete."""
@@ -103,6 +117,9 @@ class GradReducer:
 
     def finish(self):
         self.layer_done(0)
+        if self.timing is not None and self._on and self.flat.is_cuda and not _staged(self.flat, self.group):
+            self._t_end = torch.cuda.Event(enable_timing=True)
+            self._t_end.record()             # after backward's last kernel, on the compute stream
 
     def _issue(self, lo, hi):
         if not self._on:
@@ -132,6 +149,7 @@ class GradReducer:
         """Block the current stream (not the host, on GPU) until every issued bucket has landed."""
         if self._next < len(self.buckets):
             self.finish()
+        t_host = time.perf_counter() if (self.timing is not None and self._on and self._t_end is None) else None
         for work, view, host in self._pending:
             if work is not None:
                 work.wait()
@@ -139,6 +157,13 @@ class GradReducer:
                 view.copy_(host)
             if not self._use_avg:
                 view.mul_(1.0 / self.world)
+        if self._t_end is not None:
+            landed = torch.cuda.Event(enable_timing=True)
+            landed.record()                  # the compute stream reaches it once every bucket has landed
+            self.timing.append((self._t_end, landed))
+            self._t_end = None
+        elif t_host is not None and self._pending:
+            self.timing.append((1e3 * (time.perf_counter() - t_host), None))
         self._pending = []
 
 

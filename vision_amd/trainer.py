@@ -97,7 +97,7 @@ class ImageFolderDataModule:
         self.num_workers = num_workers
         self.gpu_transform = gpu_transform            # None: decided by the device the loaders run for
         self._pipeline = None
-        self._epoch_seed = 0
+        self.epoch = 0                 # set by the trainer before each epoch's train_dataloader()
 
     def _scan(self, root):
         classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
@@ -145,8 +145,9 @@ class ImageFolderDataModule:
         items = self.splits[split]
         if shuffle:
             # every rank must deal from the same permutation: draw it from a generator seeded alike
-            g = torch.Generator().manual_seed(self._epoch_seed)
-            self._epoch_seed += 1
+            # (the global seed `seed_everything` set - model_config.manual_seed in run.py, the same on every rank - and
+            # the trainer's epoch: another seed gives another order, a resumed run does not replay epoch 0's)
+            g = torch.Generator().manual_seed((torch.initial_seed() * 1000003 + self.epoch) % (2 ** 63))
             order = torch.randperm(len(items), generator=g).tolist()
         else:
             order = list(range(len(items)))
@@ -259,6 +260,8 @@ class Trainer:
         done = False
         for epoch in range(self.max_epochs):
             self.current_epoch = epoch
+            if hasattr(datamodule, "epoch"):
+                datamodule.epoch = epoch
             model.train()
             for i, batch in enumerate(datamodule.train_dataloader(self.global_rank, self.world_size)):
                 if self.dp is not None:

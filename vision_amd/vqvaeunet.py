@@ -89,7 +89,11 @@ class _FirstStageFn(torch.autograd.Function):
             rec = torch.empty((), dtype=torch.float32, device=dev)
         call("vamd_sigmoid_mse_fwd", _ptr(h), _ptr(x) if with_loss else None, _ptr(xrec), _ptr(part), _ptr(rec),
              B, Cc, H, W, eng.dt, _stream())
-        ctx.eng, ctx.tape, ctx.xrec, ctx.x, ctx.shape = eng, tape, xrec, (x if with_loss else None), (B, Cc, H, W)
+        # the output and the input go through save_for_backward: kept as plain attributes, output -> grad_fn -> ctx ->
+        # output would be a cycle the collector cannot see, and a grad-mode forward that is never backpropagated would
+        # keep its whole tape on the device
+        ctx.save_for_backward(xrec, x)
+        ctx.eng, ctx.tape, ctx.with_loss, ctx.shape = eng, tape, with_loss, (B, Cc, H, W)
         ctx.set_materialize_grads(False)
         if with_loss:
             return xrec, vq_loss, rec
@@ -99,14 +103,15 @@ class _FirstStageFn(torch.autograd.Function):
     def backward(ctx, g_xrec, g_vq, g_rec=None):
         eng = ctx.eng
         B, Cc, H, W = ctx.shape
-        dev = ctx.xrec.device
+        xrec, x = ctx.saved_tensors
+        dev = xrec.device
         dh = torch.empty((B, H, W, Cc), dtype=eng.dtype, device=dev)
         f32 = lambda t: None if t is None else t.contiguous().float()
         g_xrec, g_rec = f32(g_xrec), (None if g_rec is None else f32(g_rec).reshape(1))
-        call("vamd_sigmoid_mse_bwd", _ptr(ctx.xrec), _ptr(ctx.x) if g_rec is not None else None, _ptr(g_rec), _ptr(g_xrec),
+        call("vamd_sigmoid_mse_bwd", _ptr(xrec), _ptr(x) if (g_rec is not None and ctx.with_loss) else None, _ptr(g_rec), _ptr(g_xrec),
              _ptr(dh), B, Cc, H, W, eng.dt, _stream())
         eng.backward(ctx.tape, dh, None if g_vq is None else f32(g_vq).reshape(1))
-        ctx.tape = ctx.xrec = ctx.x = None
+        ctx.tape = None
         return None, None, None, None
 
 
