@@ -314,12 +314,17 @@ def main():
     prof = []                 # (kind, flops, start_event, end_event, shape) per MFMA conv call
     lib.vamd_launch_timing(1)
     dp.reducer.timing = []        # (event after the last backward kernel, event after the last bucket has landed) per step
+    # Host time to issue a step: taken over the first steps after the fence, while the device queue still has room.
+    # (The host may run ahead of the device by a bounded number of launches, about four steps' worth here; past that
+    # every launch call blocks until the device has retired one, and the host's pace is the device's.)
+    n_free = min(4, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
         eng.profile = prof if layers else None
         loss = step(args.warmup + i)
+        if i + 1 == n_free:
+            host_free = (time.perf_counter() - t0) / n_free
         trace(f"timed step {i} issued")
-    host_elapsed = time.perf_counter() - t0          # launches issued; the device may still be running
     fence()
     trace("timed steps done")
     elapsed = time.perf_counter() - t0
@@ -377,7 +382,7 @@ def main():
     extra["mfma_conv_ms_per_step"] = round(conv_ms / args.steps, 3)
     # host time to issue a step's launches vs the step's wall time: the step is device-bound while the first
     # stays below the second
-    extra["host_issue_ms_per_step"] = round(1e3 * host_elapsed / args.steps, 3)
+    extra["host_issue_ms_per_step"] = round(1e3 * host_free, 3)
     # the exchange step: what the gradient all-reduce costs the compute stream per step AFTER backward's last kernel
     # (everything before that overlaps with backward), the buckets it moves, and who took part
     red = dp.reducer

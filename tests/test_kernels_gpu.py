@@ -325,6 +325,51 @@ def test_conv_fwd_dgrad_wgrad(case, dts, algo):
     assert relerr(dwk.permute(0, 3, 1, 2), gw64) < TOL_F32OUT[dts]
 
 
+# Shapes with at least 512 patches of 256 pixels: served by the weight-gradient kernel that keeps the gradient tile in
+# registers.  B, H, W, Cin, Cout
+WGRAD_RESIDENT_CASES = [
+    (8, 128, 128, 64, 64),        # 8 x 32 patches, whole
+    (9, 120, 130, 64, 64),        # 8 x 32 patches, ragged right and bottom edges
+    (16, 112, 112, 64, 64),       # 16 x 16 patches
+    (11, 104, 110, 64, 64),       # 16 x 16 patches, ragged
+    (8, 128, 128, 64, 128),       # two output-channel tiles
+    (8, 128, 128, 128, 64),       # two input-channel tiles
+    (4, 56, 56, 256, 256),        # sixteen tile pairs, 16 workgroups each
+    (8, 28, 28, 512, 512),        # 64 pairs, ragged patches (28 of 32 rows and columns)
+    (16, 14, 14, 512, 512),       # one 16 x 16 patch per image, 196 of 256 pixels
+    (3, 30, 20, 192, 128),        # six pairs: 42 workgroups each, fewer patches than that
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_RESIDENT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_wgrad_resident(case):
+    """Weight and bias gradient of 3 x 3 / stride 1 layers with 64-channel tiles at sizes the resident-gradient kernel takes,
+    against fp64; with and without the bias output, in both filter layouts, twice (bit-reproducible)."""
+    B, H, W, Cin, Cout = case
+    tdt, dt = DT["bf16"]
+    gen = torch.Generator().manual_seed(sum(case))
+    x, x64 = rnd((B, Cin, H, W), tdt, gen)
+    dy, dy64 = rnd((B, Cout, H, W), tdt, gen)
+    w64 = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    (gw64,) = torch.autograd.grad(F.conv2d(x64, w64, None, padding=1), [w64], dy64)
+    d = ConvDesc(B, H, W, Cin, Cout, 3, 1, 1, 0, dt, _lib.ALGO_MFMA)
+    xn, dyn = nhwc(x), nhwc(dy)
+    wbytes = lib.vamd_conv2d_wgrad_workspace(C.byref(d))
+    wws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=DEV)
+    dwk = torch.full((Cout, 3, 3, Cin), 7.0, dtype=torch.float32, device=DEV)
+    dbk = torch.full((Cout,), 7.0, dtype=torch.float32, device=DEV)
+    call("vamd_conv2d_wgrad", C.byref(d), P(dyn), P(xn), P(dwk), P(dbk), P(wws), wbytes, S())
+    assert relerr(dwk.permute(0, 3, 1, 2), gw64) < TOL_F32OUT["bf16"]
+    assert relerr(dbk, dy64.sum((0, 2, 3))) < TOL_F32OUT["bf16"]
+    wws.fill_(0x7f)                                                  # nothing of an earlier call may be read back
+    dwo = torch.full((Cout, Cin, 3, 3), 7.0, dtype=torch.float32, device=DEV)
+    call("vamd_conv2d_wgrad_oihw", C.byref(d), P(dyn), P(xn), P(dwo), None, P(wws), wbytes, S())
+    assert torch.equal(dwo, dwk.permute(0, 3, 1, 2).contiguous())
+    dbo = torch.full((Cout,), 7.0, dtype=torch.float32, device=DEV)
+    call("vamd_conv2d_wgrad_oihw", C.byref(d), P(dyn), P(xn), P(dwo), P(dbo), P(wws), wbytes, S())
+    assert torch.equal(dwo, dwk.permute(0, 3, 1, 2).contiguous()) and torch.equal(dbo, dbk)
+
+
 SHORT_CASES = [
     # B, H, W, Cin (of the 3x3), Cout, Cin2 (of the 1x1 shortcut), k
     (2, 12, 12, 64, 64, 128, 3),       # 128-row tile, 64 output channels

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libvision_amd.so")
 PROBE_LIB = os.path.join(OUT_DIR, "libvamd_probe.so")
-SOURCES = ["elementwise.hip", "norm.hip", "conv_direct.hip", "conv_api.hip", "conv_mfma.hip", "conv_nt8.hip", "conv_thin.hip",
+SOURCES = ["elementwise.hip", "norm.hip", "conv_direct.hip", "conv_api.hip", "conv_mfma.hip", "conv_nt8.hip", "conv_wgrad_halo.hip", "conv_thin.hip",
            "conv_thin_mfma.hip", "attention.hip", "vq.hip", "image.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

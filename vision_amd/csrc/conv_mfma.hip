@@ -2530,6 +2530,7 @@ static void tn_split(const TnShape& sh, int tiles, int total_steps, int* slices_
     *steps_per_out = steps_per;
 }
 static int tn_wgrad_slices(const ConvGeom& g, int dtype) {
+    if (wgrad_halo_ok(g, dtype)) return wgrad_halo_slices(g);
     const int Ktot = g.k * g.k * g.Cin, KP = dtype == VAMD_BF16 ? 64 : 32;
     const TnShape sh = tn_shape(g.Cout, Ktot, dtype, 0);
     int slices, steps_per;
@@ -2670,7 +2671,9 @@ int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x,
     float* parts = reinterpret_cast<float*>(workspace);
     float* bias_parts = dbias ? parts + (size_t)slices * g.Cout * gp.Ktot : nullptr;
     int rc;
-    if (dtype == VAMD_BF16)
+    if (wgrad_halo_ok(g, dtype))
+        rc = launch_wgrad_halo(g, dy, x, parts, bias_parts, st);
+    else if (dtype == VAMD_BF16)
         rc = launch_tn<bf16_t>(gp, (const bf16_t*)dy, (const bf16_t*)x, g.Cout, g.Cout, gp.Ktot, parts, 1, 0, 0, 0, 0, nullptr, 1.f, bias_parts, 1, st);
     else
         rc = launch_tn<float>(gp, (const float*)dy, (const float*)x, g.Cout, g.Cout, gp.Ktot, parts, 1, 0, 0, 0, 0, nullptr, 1.f, bias_parts, 1, st);

@@ -325,4 +325,11 @@ int nt8_stats_parts(const Gather& gp, int N, const Epilogue& ep);   // workgroup
 int launch_nt8(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep, void* y,
                double flops, double executed, hipStream_t st);
 
+// Weight gradient with the gradient tile resident in registers (conv_wgrad_halo.hip): 3 x 3 / stride 1 layers whose
+// channel counts are small multiples of 64, bf16.  One partial product [Cout][9][Cin] (+ [Cout] bias sums) per slice.
+struct ConvGeom;
+bool wgrad_halo_ok(const ConvGeom& g, int dtype);
+int wgrad_halo_slices(const ConvGeom& g);
+int launch_wgrad_halo(const ConvGeom& g, const void* dy, const void* x, float* parts, float* bias_parts, hipStream_t st);
+
 }  // namespace vamd
