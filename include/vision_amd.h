@@ -157,6 +157,26 @@ int vamd_conv2d_wgrad_oihw(const vamd_conv_desc* d, const void* dy, const void* 
                            void* workspace, size_t workspace_bytes, void* stream);
 size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d);
 
+/* Convolution whose INPUT is BatchNorm2d + LeakyReLU of a stored tensor x (training or eval mode), with that
+ * normalisation applied INSIDE the kernels: reference models/ddpm.py:49-60, `self.block1 = Sequential(BatchNorm2d, act,
+ * Conv2d)` / `self.block2 = Sequential(BatchNorm2d, act, Dropout(0), Conv2d)` as one operator.  The kernels stage
+ * x's halo patch in LDS once and replace every staged element by
+ *     round_to_dtype(leaky_relu(fma(x, in_scale[c], in_shift[c]), in_slope))
+ * (what vamd_scale_shift_act would have stored; padding stays zero), so the normalised tensor is never written or read:
+ * the results are bit-identical to vamd_scale_shift_act followed by vamd_conv2d_fwd(_stats) / vamd_conv2d_wgrad_oihw.
+ * in_scale / in_shift: [Cin] fp32, 16-byte aligned (vamd_bn_finalize's scale and shift); 0 <= in_slope <= 1.
+ * vamd_conv2d_prenorm_supported: 1 when BOTH the forward and the weight gradient of the descriptor have such a kernel
+ * (bf16, 3x3 stride 1, 64 input channels, 64 or 128 output channels, enough 256-pixel patches to fill the chip), so
+ * that a caller may drop the normalised tensor altogether; the input gradient does not need it.
+ * `stats` of the forward: NULL, or the buffer of vamd_conv2d_fwd_stats (vamd_conv2d_stats_parts rows). */
+int vamd_conv2d_prenorm_supported(const vamd_conv_desc* d);
+int vamd_conv2d_fwd_prenorm(const vamd_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
+                            float in_slope, const void* w, const float* bias, const float* temb, const void* residual,
+                            const void* residual2, void* y, float* stats, void* stream);
+int vamd_conv2d_wgrad_prenorm_oihw(const vamd_conv_desc* d, const void* dy, const void* x, const float* in_scale,
+                                   const float* in_shift, float in_slope, float* dw, float* dbias, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* Tuning control, process-wide: with a scratch buffer in the descriptor, 3x3 / 4x4 layers that have fewer tiles than the
  * chip has CUs and a reduction of at least 8 K-steps per filter row run one workgroup set per filter row and add the
  * fp32 partial products in a second, small kernel (same epilogue terms, one rounding; results differ from the unsplit

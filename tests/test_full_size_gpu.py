@@ -223,6 +223,45 @@ def test_full_batch_forward_is_batch_independent_and_step_is_reproducible(no_spl
     assert err < 1e-6, err
 
 
+def test_in_kernel_input_normalisation_changes_no_bit_of_a_training_step(monkeypatch):
+    """The opt-in form of BatchNorm + LeakyReLU in front of the 64-channel 3 x 3 convolutions (normalised inside the
+    forward and weight-gradient kernels, no normalised tensor stored) against the default form: same loss, same
+    gradients, same running statistics, bit for bit, on a 16-image 224 x 224 training step (conv2 of the first block,
+    conv1 of the third and conv2 of the sixth block take that path)."""
+    import vision_amd.engine as engine_mod
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    B = 16
+    img = torch.rand((B, 3, 224, 224), device=DEV, generator=gen)
+    eps = torch.randn((B, 3, 224, 224), device=DEV, generator=gen)
+    tt = torch.rand((B, 1, 1, 1), device=DEV, generator=gen)
+    runs = []
+    for fused in (False, True):
+        monkeypatch.setattr(engine_mod, "FUSE_TRAIN_NORM", fused)
+        model, cfg, _, _ = _butterfly_model("bf16")
+        model.train()
+        eng = model._ensure_engine()
+        taken = [c.name for c in eng.all_convs() if c.k == 3 and c.plan(B, *_in_hw(eng, c)).prenorm]
+        assert bool(taken) == fused, taken
+        loss = model.p_loss(img, noises=eps, diffusion_times=tt)
+        loss.backward()
+        runs.append((loss.detach().clone(), eng.flat_g.clone(), eng.flat_b.clone()))
+        del model, eng
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][2], runs[1][2])
+    # (the thin-channel layers' bias gradients use fp32 atomics: compare everything else exactly)
+    same = runs[0][1] == runs[1][1]
+    assert same.float().mean().item() > 0.9999 and ((runs[0][1] - runs[1][1]).norm() / runs[0][1].norm()).item() < 1e-6
+
+
+def _in_hw(eng, conv):
+    """Input height and width of a convolution of the 224 x 224 butterfly UNet, from its position in the plan."""
+    for layer in eng.layers:
+        if conv in layer.convs:
+            r = int(layer.spec.res_in)
+            return r, r
+    return 224, 224
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_full_resolution_sampler_against_oracle(mode):
     """Three sampler steps on two 224x224 images against the oracle (fp32, as the reference runs

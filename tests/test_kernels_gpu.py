@@ -370,6 +370,82 @@ def test_conv_wgrad_resident(case):
     assert torch.equal(dwo, dwk.permute(0, 3, 1, 2).contiguous()) and torch.equal(dbo, dbk)
 
 
+# Shapes whose forward runs on the resident-filter kernel and whose weight gradient on the resident-gradient kernel (at
+# least 512 patches of 256 pixels, 64 input channels).  B, H, W, Cout
+PRENORM_CASES = [
+    (8, 128, 128, 64),            # 8 x 32 patches, whole
+    (9, 120, 130, 64),            # ragged right and bottom edges: padding must stay zero after the affine map
+    (16, 112, 112, 64),           # 16 x 16 patches
+    (11, 104, 110, 128),          # two column tiles, ragged 16 x 16 patches
+]
+
+
+@pytest.mark.parametrize("case", PRENORM_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_with_input_normalised_in_the_kernel(case):
+    """vamd_conv2d_fwd_prenorm / vamd_conv2d_wgrad_prenorm_oihw (BatchNorm + LeakyReLU of the input applied to the staged
+    patch in LDS) against vamd_scale_shift_act followed by the plain calls: bit-identical outputs, statistics and
+    gradients; and against fp64 on the normalised tensor."""
+    B, H, W, Cout = case
+    Cin = 64
+    tdt, dt = DT["bf16"]
+    gen = torch.Generator().manual_seed(sum(case))
+    x, x64 = rnd((B, H, W, Cin), tdt, gen)
+    dy, dy64 = rnd((B, H, W, Cout), tdt, gen)
+    res, _ = rnd((B, H, W, Cout), tdt, gen)
+    w64 = torch.randn((Cout, Cin, 3, 3), generator=gen, dtype=torch.float64) / 24.0
+    wf, _ = pack_weights(w64, tdt, dt)
+    bias = torch.randn(Cout, generator=gen).to(DEV)
+    temb = torch.randn((B, Cout), generator=gen).to(DEV)
+    scale = (torch.rand(Cin, generator=gen) + 0.5).to(DEV)
+    shift = torch.randn(Cin, generator=gen).to(DEV)               # non-zero: act(shift) != 0 would leak into the padding
+    slope = 0.01
+    d = ConvDesc(B, H, W, Cin, Cout, 3, 1, 1, 0, dt, _lib.ALGO_AUTO)
+    assert lib.vamd_conv2d_prenorm_supported(C.byref(d)) == 1
+    a = torch.empty_like(x)
+    call("vamd_scale_shift_act", P(x), P(scale), P(shift), None, slope, 1.0, P(a), 1, B * H * W, Cin, dt, S())
+    nparts = lib.vamd_conv2d_stats_parts(C.byref(d))
+    assert nparts > 0
+    y0, y1 = torch.empty((B, H, W, Cout), dtype=tdt, device=DEV), torch.empty((B, H, W, Cout), dtype=tdt, device=DEV)
+    st0 = torch.zeros((nparts, Cout, 2), dtype=torch.float32, device=DEV)
+    st1 = torch.zeros_like(st0)
+    call("vamd_conv2d_fwd_stats", C.byref(d), P(a), P(wf), P(bias), P(temb), P(res), None, P(y0), P(st0), S())
+    call("vamd_conv2d_fwd_prenorm", C.byref(d), P(x), P(scale), P(shift), slope, P(wf), P(bias), P(temb), P(res), None, P(y1),
+         P(st1), S())
+    assert torch.equal(y0, y1) and torch.equal(st0, st1)
+    y2 = torch.empty_like(y0)
+    call("vamd_conv2d_fwd_prenorm", C.byref(d), P(x), P(scale), P(shift), slope, P(wf), None, None, None, None, P(y2), None, S())
+    a64 = a.double().cpu().permute(0, 3, 1, 2)
+    ref = F.conv2d(a64, wf.double().cpu().permute(0, 3, 1, 2), None, padding=1).permute(0, 2, 3, 1)
+    assert relerr(y2, ref) < TOL_OUT["bf16"]
+    # weight gradient
+    wbytes = lib.vamd_conv2d_wgrad_workspace(C.byref(d))
+    wws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=DEV)
+    g0 = torch.full((Cout, Cin, 3, 3), 7.0, dtype=torch.float32, device=DEV)
+    g1 = torch.full_like(g0, 3.0)
+    b0, b1 = torch.full((Cout,), 7.0, device=DEV), torch.full((Cout,), 3.0, device=DEV)
+    call("vamd_conv2d_wgrad_oihw", C.byref(d), P(dy), P(a), P(g0), P(b0), P(wws), wbytes, S())
+    wws.fill_(0x7f)
+    call("vamd_conv2d_wgrad_prenorm_oihw", C.byref(d), P(dy), P(x), P(scale), P(shift), slope, P(g1), P(b1), P(wws), wbytes, S())
+    assert torch.equal(g0, g1) and torch.equal(b0, b1)
+    w0 = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    (gw64,) = torch.autograd.grad(F.conv2d(a64, w0, None, padding=1), [w0], dy64.permute(0, 3, 1, 2))
+    assert relerr(g1, gw64) < TOL_F32OUT["bf16"]
+
+
+def test_prenorm_refuses_what_it_cannot_do():
+    dt = DT["bf16"][1]
+    for shape in [(2, 16, 16, 64, 64, 3, 1), (8, 128, 128, 128, 128, 3, 1), (8, 128, 128, 64, 64, 1, 1), (8, 128, 128, 64, 64, 3, 2)]:
+        B, H, W, Cin, Cout, k, stride = shape
+        d = ConvDesc(B, H, W, Cin, Cout, k, stride, 1 if k == 3 else 0, 0, dt, _lib.ALGO_AUTO)
+        assert lib.vamd_conv2d_prenorm_supported(C.byref(d)) == 0
+        t = torch.zeros(B * H * W * max(Cin, Cout), dtype=torch.bfloat16, device=DEV)
+        c = torch.zeros(max(Cin, Cout), dtype=torch.float32, device=DEV)
+        rc = lib.vamd_conv2d_fwd_prenorm(C.byref(d), P(t), P(c), P(c), 0.01, P(t), None, None, None, None, P(t), None, S())
+        assert rc == -2 or rc < 0, rc
+    d = ConvDesc(8, 128, 128, 64, 64, 3, 1, 1, 0, DT["f32"][1], _lib.ALGO_AUTO)
+    assert lib.vamd_conv2d_prenorm_supported(C.byref(d)) == 0
+
+
 SHORT_CASES = [
     # B, H, W, Cin (of the 3x3), Cout, Cin2 (of the 1x1 shortcut), k
     (2, 12, 12, 64, 64, 128, 3),       # 128-row tile, 64 output channels

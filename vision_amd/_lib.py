@@ -97,6 +97,9 @@ SIGNATURES = {
     "vamd_conv2d_wgrad": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
     "vamd_conv2d_wgrad_oihw": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
     "vamd_conv2d_wgrad_workspace": (_z, [_d]),
+    "vamd_conv2d_prenorm_supported": (_i, [_d]),
+    "vamd_conv2d_fwd_prenorm": (_i, [_d, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "vamd_conv2d_wgrad_prenorm_oihw": (_i, [_d, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p]),
     "vamd_conv_splitk": (_i, [_i]),
     "vamd_conv2d_uses_mfma": (_i, [_d, _i]),
     "vamd_repack_weight": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

@@ -156,6 +156,52 @@ int vamd_conv2d_fwd_act(const vamd_conv_desc* d, const void* x, const void* w, c
                              as_stream(stream));
 }
 
+int vamd_conv2d_prenorm_supported(const vamd_conv_desc* d) {
+    ConvGeom g;
+    if (conv_geom(d, &g, "vamd_conv2d_prenorm_supported")) return 0;
+    if (pick(d->algo, conv_thin_supported(g, d->dtype), conv_fwd_mfma_supported(g, d->dtype), "", g) != kMfma) return 0;
+    if (pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), "", g) != kMfma) return 0;
+    if (conv_wgrad_up4_mfma_supported(g, d->dtype)) return 0;
+    return conv_prenorm_mfma_supported(g, d->dtype) ? 1 : 0;
+}
+
+int vamd_conv2d_fwd_prenorm(const vamd_conv_desc* d, const void* x, const float* in_scale, const float* in_shift,
+                            float in_slope, const void* w, const float* bias, const float* temb, const void* residual,
+                            const void* residual2, void* y, float* stats, void* stream) {
+    const char* who = "vamd_conv2d_fwd_prenorm";
+    ConvGeom g;
+    int rc = conv_geom(d, &g, who);
+    if (rc) return rc;
+    VAMD_REQUIRE(x && w && y && in_scale && in_shift, "%s: null tensor", who);
+    VAMD_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)in_scale % 16 == 0 &&
+                 (uintptr_t)in_shift % 16 == 0 && (uintptr_t)residual % 16 == 0 && (uintptr_t)residual2 % 16 == 0,
+                 "%s: tensors must be 16-byte aligned", who);
+    VAMD_REQUIRE(in_slope >= 0.f && in_slope <= 1.f, "%s: slope outside [0, 1]", who);
+    if (!vamd_conv2d_prenorm_supported(d))
+        return fail(VAMD_EUNSUPPORTED, "%s: no kernel normalises the input for Cin=%d Cout=%d k=%d stride=%d H=%d W=%d B=%d (ask "
+                    "vamd_conv2d_prenorm_supported first)", who, g.Cin, g.Cout, g.k, g.stride, g.H, g.W, g.B);
+    return conv_fwd_prenorm_mfma(g, d->dtype, x, in_scale, in_shift, in_slope, w, bias, temb, residual, residual2, y, stats,
+                                 as_stream(stream));
+}
+
+int vamd_conv2d_wgrad_prenorm_oihw(const vamd_conv_desc* d, const void* dy, const void* x, const float* in_scale,
+                                   const float* in_shift, float in_slope, float* dw, float* dbias, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    const char* who = "vamd_conv2d_wgrad_prenorm_oihw";
+    ConvGeom g;
+    int rc = conv_geom(d, &g, who);
+    if (rc) return rc;
+    VAMD_REQUIRE(dy && x && dw && in_scale && in_shift, "%s: null tensor", who);
+    VAMD_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dw % 16 == 0 && (uintptr_t)workspace % 16 == 0 &&
+                 (uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0, "%s: tensors must be 16-byte aligned", who);
+    VAMD_REQUIRE(in_slope >= 0.f && in_slope <= 1.f, "%s: slope outside [0, 1]", who);
+    if (!vamd_conv2d_prenorm_supported(d))
+        return fail(VAMD_EUNSUPPORTED, "%s: no kernel normalises the input for Cin=%d Cout=%d k=%d stride=%d H=%d W=%d B=%d (ask "
+                    "vamd_conv2d_prenorm_supported first)", who, g.Cin, g.Cout, g.k, g.stride, g.H, g.W, g.B);
+    return conv_wgrad_mfma(g, d->dtype, dy, x, dw, dbias, 1, workspace, workspace_bytes, as_stream(stream), in_scale, in_shift,
+                           in_slope);
+}
+
 int vamd_conv2d_stats_parts(const vamd_conv_desc* d) {
     ConvGeom g;
     if (conv_geom(d, &g, "vamd_conv2d_stats_parts")) return 0;

@@ -1067,7 +1067,7 @@ constexpr int kHaloRows = 344;                             // 10 x 34 = 340 (or 
 constexpr int kHaloBuf = kHaloRows * 128;
 constexpr int halo_lds_bytes(int ntaps) { return ntaps * 64 * 128 + 2 * kHaloBuf; }   // resident filter + two patches
 
-template <int EPI, int KR, int KS>                          // EPI: 0 plain, 1 statistics, 2 fused normalise
+template <int EPI, int KR, int KS, bool PRE = false>        // EPI: 0 plain, 1 statistics, 2 fused normalise; PRE: normalise the input
 __global__ void __launch_bounds__(512, 1)
 conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, Epilogue ep,
                      void* __restrict__ yout) {
@@ -1115,11 +1115,13 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
         h_chunk[j] = ((lane & 7) ^ (hp & 7)) * 8;
     }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x);
+    uint32_t staged_ok = 0;                               // PRE: bit j = piece j of the patch staged last holds a pixel of the image
     auto stage = [&](int tile, int buf) {
         const int tx = tile % ha.tiles_w;
         const int ty = (tile / ha.tiles_w) % ha.tiles_h;
         const int b = tile / (ha.tiles_w * ha.tiles_h);
         const int h0 = ty * PH - 1, w0 = tx * PW - 1;
+        staged_ok = 0;
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
             if ((wave_s + 8 * j) * 8 >= kHaloRows) continue;               // uniform: no such piece
@@ -1127,6 +1129,35 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
             const bool ok = h_rc[j] >= 0 && (unsigned)hi < (unsigned)ha.H && (unsigned)wi < (unsigned)ha.W;
             const int off = ((b * ha.H + hi) * ha.W + wi) * 64 + h_chunk[j];
             load16_lds(rx, (uint32_t)off * 2u, ok, halo + buf * kHaloBuf + (wave_s + 8 * j) * 1024);
+            if constexpr (PRE) staged_ok |= ok ? 1u << j : 0u;
+        }
+    };
+    // PRE: a lane normalises the 16-byte slots it loaded itself (its own loads have landed once its vmcnt is 0: no
+    // barrier in between).  Slot (lane & 7) of row (lane >> 3) of every piece holds the same eight channels, so their
+    // sixteen coefficients stay in registers; slots of padding pixels keep the zeros the hardware wrote.
+    f32x2_t psc[4], psh[4];
+    if constexpr (PRE) {
+        const int c0 = h_chunk[0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            psc[e] = *reinterpret_cast<const f32x2_t*>(ep.pre_scale + c0 + 2 * e);
+            psh[e] = *reinterpret_cast<const f32x2_t*>(ep.pre_shift + c0 + 2 * e);
+        }
+    }
+    auto normalise = [&](int buf, uint32_t okbits) {
+        // every wave holds pieces 0 .. NPC-2; they go through together (independent chains of arithmetic), the last piece
+        // exists for the first waves only
+        unsigned char* base = halo + buf * kHaloBuf + wave_s * 1024 + lane * 16;
+        u32x4_t v[NPC - 1];
+#pragma unroll
+        for (int j = 0; j < NPC - 1; ++j) v[j] = *reinterpret_cast<const u32x4_t*>(base + j * 8192);
+#pragma unroll
+        for (int j = 0; j < NPC - 1; ++j) v[j] = norm_act_piece(v[j], psc, psh, ep.pre_slope, 0u - ((okbits >> j) & 1u));
+#pragma unroll
+        for (int j = 0; j < NPC - 1; ++j) *reinterpret_cast<u32x4_t*>(base + j * 8192) = v[j];
+        if ((wave_s + 8 * (NPC - 1)) * 8 < kHaloRows) {                   // uniform
+            u32x4_t* slot = reinterpret_cast<u32x4_t*>(base + (NPC - 1) * 8192);
+            *slot = norm_act_piece(*slot, psc, psh, ep.pre_slope, 0u - ((okbits >> (NPC - 1)) & 1u));
         }
     };
 
@@ -1165,6 +1196,10 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
     init_acc();
     for (; tile < ha.ntiles; tile += nblk) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PRE) {                              // own slots: this wave's loads have landed, no barrier needed yet
+            normalise(buf, staged_ok);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                     // this tile's patch (and the filter) is in LDS; every wave is past the previous tile
         if (tile + nblk < ha.ntiles) stage(tile + nblk, buf ^ 1);
         // ---- this tile's rows, and its epilogue operands: loaded now, used after the 144 MFMAs
@@ -1964,12 +1999,24 @@ static int launch_c64_halo(const HaloArgs& ha, const bf16_t* x, const bf16_t* w,
         int rc = set_lds_limit(conv_c64_halo_kernel<false, KR, KS>, LDS, "conv_c64_halo");
         if (!rc) rc = set_lds_limit(conv_c64_halo_kernel<true, KR, KS>, LDS, "conv_c64_halo");
         if (!rc) rc = set_lds_limit(conv_c64_halo_kernel<2, KR, KS>, LDS, "conv_c64_halo");
+        if constexpr (KR == 3) {
+            if (!rc) rc = set_lds_limit(conv_c64_halo_kernel<0, KR, KS, true>, LDS, "conv_c64_halo");
+            if (!rc) rc = set_lds_limit(conv_c64_halo_kernel<1, KR, KS, true>, LDS, "conv_c64_halo");
+        }
         if (rc) return rc;
         configured = true;
     }
     const int blocks = c64_halo_blocks(ha.ntiles, ha.n_tiles * ha.ncls);
     TimedLaunch timed(TIMED_NT, take_flops(flops), flops, st);
-    if (ep.act_scale) hipLaunchKernelGGL((conv_c64_halo_kernel<2, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
+    if (ep.pre_scale) {
+        if constexpr (KR == 3) {
+            if (ep.act_scale) return fail(VAMD_EUNSUPPORTED, "conv_c64_halo: input normalisation and fused output normalisation together");
+            if (ep.stats) hipLaunchKernelGGL((conv_c64_halo_kernel<1, KR, KS, true>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
+            else hipLaunchKernelGGL((conv_c64_halo_kernel<0, KR, KS, true>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
+        } else {
+            return fail(VAMD_EUNSUPPORTED, "conv_c64_halo: input normalisation on a class filter");
+        }
+    } else if (ep.act_scale) hipLaunchKernelGGL((conv_c64_halo_kernel<2, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
     else if (ep.stats) hipLaunchKernelGGL((conv_c64_halo_kernel<true, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
     else hipLaunchKernelGGL((conv_c64_halo_kernel<false, KR, KS>), dim3(blocks), dim3(512), LDS, st, ha, x, w, ep, y);
     VAMD_LAUNCH_OK("conv_c64_halo");
@@ -2133,7 +2180,10 @@ static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw
                   const ClassSet* classes = nullptr) {
     if (!classes) {
         const int nsplit = nt_split_rows(gp, N, ldc, ep, batch, sizeof(T));
-        if (nsplit > 0) return run_nt_split<T>(gp, (const T*)x, (const T*)w, N, ldw, ep, y, nsplit, st);
+        if (nsplit > 0) {
+            if (ep.pre_scale) return fail(VAMD_EUNSUPPORTED, "conv: no kernel normalises the input of this shape (split reduction)");
+            return run_nt_split<T>(gp, (const T*)x, (const T*)w, N, ldw, ep, y, nsplit, st);
+        }
     }
     if constexpr (sizeof(T) == 2) {
         int pwl, tw, th, nt;
@@ -2143,6 +2193,7 @@ static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw
             return launch_c64_halo<3, 3>(ha, (const bf16_t*)x, (const bf16_t*)w, ep, y, 2.0 * gp.M * N * 576, st);
         }
     }
+    if (ep.pre_scale) return fail(VAMD_EUNSUPPORTED, "conv: only the resident-filter kernel normalises its input (ask vamd_conv2d_prenorm_supported)");
     if constexpr (sizeof(T) == 2) {
         if (!classes && nt8_applicable(gp, N, ldw, ldc, ep, batch)) {
             const double fl = 2.0 * gp.M * N * gp.Ktot;
@@ -2213,6 +2264,28 @@ int conv_fwd_mfma(const ConvGeom& g, int dtype, const void* x, const void* w, co
     Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats, (unsigned char*)g.scratch, g.scratch_bytes};
     if (dtype == VAMD_BF16) return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
     return run_nt<float>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
+}
+
+// The forward (and weight gradient) of a convolution whose INPUT is BatchNorm + LeakyReLU of a stored tensor, with the
+// normalisation applied inside the kernels (no normalised tensor in memory): shapes that the resident-filter forward
+// kernel AND the resident-gradient weight-gradient kernel both take.
+bool conv_prenorm_mfma_supported(const ConvGeom& g, int dtype) {
+    if (dtype != VAMD_BF16 || nt_classic() || g.up) return false;
+    const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
+    const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
+    int pwl, tw, th, nt;
+    if (!c64_halo_gather(gp, g.Cout, gp.Ktot, g.Cout, ep, 1) || !c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return false;
+    if (nt_split_rows(gp, g.Cout, g.Cout, ep, 1, 2) > 0) return false;
+    return wgrad_halo_ok(g, dtype);
+}
+
+int conv_fwd_prenorm_mfma(const ConvGeom& g, int dtype, const void* x, const float* pre_scale, const float* pre_shift,
+                          float pre_slope, const void* w, const float* bias, const float* temb, const void* res,
+                          const void* res2, void* y, float* stats, hipStream_t st) {
+    Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
+    Epilogue ep{bias, temb, res, res2, 1.0f, 0, stats, (unsigned char*)g.scratch, g.scratch_bytes, nullptr, nullptr, 0.f, nullptr,
+                pre_scale, pre_shift, pre_slope};
+    return run_nt<bf16_t>(gp, x, w, g.Cout, gp.Ktot, g.Cout, ep, y, 1, 0, 0, 0, st);
 }
 
 // The forward with the consumer's eval-mode BatchNorm + LeakyReLU folded into the epilogue.  Kernels that implement
@@ -2662,7 +2735,8 @@ size_t conv_wgrad_mfma_workspace(const ConvGeom& g, int dtype) {
 }
 
 int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
-                    int oihw, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                    int oihw, void* workspace, size_t workspace_bytes, hipStream_t st, const float* pre_scale,
+                    const float* pre_shift, float pre_slope) {
     Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
     if (!workspace || workspace_bytes < conv_wgrad_mfma_workspace(g, dtype))
         return fail(VAMD_EINVAL, "conv_wgrad_mfma: needs %zu workspace bytes", conv_wgrad_mfma_workspace(g, dtype));
@@ -2672,7 +2746,9 @@ int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x,
     float* bias_parts = dbias ? parts + (size_t)slices * g.Cout * gp.Ktot : nullptr;
     int rc;
     if (wgrad_halo_ok(g, dtype))
-        rc = launch_wgrad_halo(g, dy, x, parts, bias_parts, st);
+        rc = launch_wgrad_halo(g, dy, x, parts, bias_parts, st, pre_scale, pre_shift, pre_slope);
+    else if (pre_scale)
+        return fail(VAMD_EUNSUPPORTED, "conv_wgrad_mfma: only the resident-gradient kernel normalises its input (ask vamd_conv2d_prenorm_supported)");
     else if (dtype == VAMD_BF16)
         rc = launch_tn<bf16_t>(gp, (const bf16_t*)dy, (const bf16_t*)x, g.Cout, g.Cout, gp.Ktot, parts, 1, 0, 0, 0, 0, nullptr, 1.f, bias_parts, 1, st);
     else

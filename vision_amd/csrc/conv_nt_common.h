@@ -76,6 +76,12 @@ struct Epilogue {
     const float* act_shift;
     float act_slope;
     void* raw;
+    // BatchNorm + LeakyReLU of the INPUT applied by the kernel itself (pre_scale != NULL; resident-filter kernel only):
+    // x is the tensor before the normalisation and every staged element becomes round(leaky(fma(x, pre_scale[c],
+    // pre_shift[c]))) in LDS -- bit for bit what a separate normalise pass would have stored -- while padding stays zero.
+    const float* pre_scale;
+    const float* pre_shift;
+    float pre_slope;
 };
 
 // Up to four convolutions of one layer in one launch (the output-parity classes of a stride-2 input
@@ -111,6 +117,27 @@ __device__ __forceinline__ void load16_lds(__amdgpu_buffer_rsrc_t r, uint32_t by
     byte_off = (byte_off & 0x3f0u);
 #endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LPTR(lds), 16, (int)(ok ? byte_off : kNoLoad), 0, 0, 0);
+}
+
+// BatchNorm + LeakyReLU of eight bf16 values held as four 32-bit words, in place: round(leaky(fma(x, sc, sh))) per element,
+// bit for bit what scale_shift_act_kernel stores for slopes in [0, 1] (max(z, slope * z) == z > 0 ? z : slope * z there).
+// Packed fp32 multiply-adds and a two-operand conversion: 32 vector instructions per 16-byte piece.  keep = 0 clears the
+// piece (a padding pixel, whose zeros must survive the affine map), keep = ~0 leaves it.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+__device__ __forceinline__ u32x4_t norm_act_piece(u32x4_t v, const f32x2_t (&sc)[4], const f32x2_t (&sh)[4], float slope,
+                                                   uint32_t keep) {
+    const f32x2_t sl = {slope, slope};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const f32x2_t x = {__builtin_bit_cast(float, v[e] << 16), __builtin_bit_cast(float, v[e] & 0xffff0000u)};
+        const f32x2_t z = __builtin_elementwise_fma(x, sc[e], sh[e]);
+        const f32x2_t zs = z * sl;
+        const f32x2_t m = {fmaxf(z[0], zs[0]), fmaxf(z[1], zs[1])};
+        v[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(m, bf16x2_t)) & keep;
+    }
+    return v;
 }
 
 template <typename T> struct ElemTraits;
@@ -330,6 +357,7 @@ int launch_nt8(const Gather& gp, const void* x, const void* w, int N, int ldw, i
 struct ConvGeom;
 bool wgrad_halo_ok(const ConvGeom& g, int dtype);
 int wgrad_halo_slices(const ConvGeom& g);
-int launch_wgrad_halo(const ConvGeom& g, const void* dy, const void* x, float* parts, float* bias_parts, hipStream_t st);
+int launch_wgrad_halo(const ConvGeom& g, const void* dy, const void* x, float* parts, float* bias_parts, hipStream_t st,
+                      const float* pre_scale = nullptr, const float* pre_shift = nullptr, float pre_slope = 0.f);
 
 }  // namespace vamd

@@ -82,7 +82,13 @@ int conv_wgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void
 bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype);
 size_t conv_wgrad_mfma_workspace(const ConvGeom& g, int dtype);
 int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
-                    int oihw, void* workspace, size_t workspace_bytes, hipStream_t st);
+                    int oihw, void* workspace, size_t workspace_bytes, hipStream_t st, const float* pre_scale = nullptr,
+                    const float* pre_shift = nullptr, float pre_slope = 0.f);
+// input = BatchNorm + LeakyReLU of a stored tensor, applied inside the forward and weight-gradient kernels
+bool conv_prenorm_mfma_supported(const ConvGeom& g, int dtype);
+int conv_fwd_prenorm_mfma(const ConvGeom& g, int dtype, const void* x, const float* pre_scale, const float* pre_shift,
+                          float pre_slope, const void* w, const float* bias, const float* temb, const void* res,
+                          const void* res2, void* y, float* stats, hipStream_t st);
 
 // batched products for the attention core on the MFMA kernels (rows may be padded: ld = row stride)
 bool bmm_nt_mfma_supported(int M, int N, int K, int lda, int ldb, int ldc, int dtype, int out_f32);

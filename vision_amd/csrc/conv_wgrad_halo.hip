@@ -34,6 +34,11 @@ struct WgHaloArgs {
     int Cin, Cout;                  // multiples of 64
     int n_tiles, c_tiles;           // Cout / 64, Cin / 64: a workgroup owns one (output tile, input tile) pair
     int ldc;                        // 9 * Cin: row length of a partial product [Cout][9][Cin]
+    // PRE: X is BatchNorm + LeakyReLU of the stored tensor, applied to the halo patch in LDS:
+    // round(leaky(fma(x, pre_scale[c], pre_shift[c]))), what a separate normalise pass would have stored
+    const float* pre_scale;
+    const float* pre_shift;
+    float pre_slope;
 };
 
 namespace {
@@ -58,9 +63,12 @@ constexpr int wgh_halo_rows(int pwl) { return (((256 >> pwl) + 2) * ((1 << pwl) 
 constexpr int kWghDyBytes = 256 * 128;
 constexpr int wgh_buf_bytes(int pwl) { return wgh_halo_rows(pwl) * 128 + kWghDyBytes; }
 constexpr int kWghRedBytes = 4 * 37 * 64 * 16;           // 36 accumulator tiles + the bias sums of waves 4-7, 16 B per lane
-constexpr int wgh_lds_bytes(int pwl) { return 2 * wgh_buf_bytes(pwl) > kWghRedBytes ? 2 * wgh_buf_bytes(pwl) : kWghRedBytes; }
+constexpr int kWghCoefBytes = 2 * 64 * 4;                // PRE: scale and shift of the workgroup's 64 input channels
+constexpr int wgh_lds_bytes(int pwl) {
+    return (2 * wgh_buf_bytes(pwl) > kWghRedBytes ? 2 * wgh_buf_bytes(pwl) : kWghRedBytes) + kWghCoefBytes;
+}
 
-template <int PWL>
+template <int PWL, bool PRE>
 __global__ void __launch_bounds__(512, 1)
 wgrad_halo_kernel(WgHaloArgs a, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ parts,
                   float* __restrict__ bias_parts) {
@@ -96,12 +104,14 @@ wgrad_halo_kernel(WgHaloArgs a, const bf16_t* __restrict__ dy, const bf16_t* __r
         ds[j] = ((nt * 64 + (((lane & 7) ^ wgh_swz(pc)) << 3)) << 16) | (pr << 8) | pc;
     }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x), rdy = make_rsrc(dy);
+    uint32_t staged_ok = 0;                               // PRE: bit j = halo piece j of the patch staged last holds a pixel of the image
     auto stage = [&](int tile, int buf) {
         const int tx = tile % a.tiles_w;
         const int ty = (tile / a.tiles_w) % a.tiles_h;
         const int b = tile / (a.tiles_w * a.tiles_h);
         const int h0 = ty * PH, w0 = tx * PW;
         unsigned char* base = smem + buf * BUF + wave_s * 1024;
+        staged_ok = 0;
 #pragma unroll
         for (int j = 0; j < NPCX; ++j) {
             if ((wave_s + 8 * j) * 8 >= HROWS) continue;                     // uniform: no such piece
@@ -109,6 +119,7 @@ wgrad_halo_kernel(WgHaloArgs a, const bf16_t* __restrict__ dy, const bf16_t* __r
             const bool ok = xs[j] >= 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
             const int off = ((b * a.H + hi) * a.W + wi) * a.Cin + ((xs[j] >> 16) & 0x7fff);
             load16_lds(rx, (uint32_t)off * 2u, ok, base + j * 8192);
+            if constexpr (PRE) staged_ok |= ok ? 1u << j : 0u;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -116,6 +127,44 @@ wgrad_halo_kernel(WgHaloArgs a, const bf16_t* __restrict__ dy, const bf16_t* __r
             const bool ok = hi < a.H && wi < a.W;                             // pixels past the image contribute zeros
             const int off = ((b * a.H + hi) * a.W + wi) * a.Cout + (ds[j] >> 16);
             load16_lds(rdy, (uint32_t)off * 2u, ok, base + XB + j * 8192);
+        }
+    };
+
+    // PRE: a lane normalises the 16-byte slots it loaded itself, before the patch's barrier (its own loads have landed
+    // once its vmcnt is 0); the slot's eight channels depend on the pixel's column, so the coefficients come from a
+    // table in LDS behind the two buffers.  Slots of padding pixels keep the zeros the hardware wrote.
+    float* coef = reinterpret_cast<float*>(smem + wgh_lds_bytes(PWL) - kWghCoefBytes);     // [2][64]
+    if constexpr (PRE) {
+        if (tid < 128) coef[tid] = (tid < 64 ? a.pre_scale : a.pre_shift)[ct * 64 + (tid & 63)];
+        __syncthreads();
+    }
+    auto normalise = [&](int buf, uint32_t okbits) {
+        // two pieces at a time (eight independent chains of arithmetic; registers do not allow more next to the 148
+        // accumulators): every wave holds pieces 0 .. NPCX-2, the last one exists for the first waves only
+        static_assert(NPCX == 6, "pieces in pairs; the sixth exists for the first waves only");
+        unsigned char* base = smem + buf * BUF + wave_s * 1024 + lane * 16;
+        auto one = [&](int j, u32x4_t& v, f32x2_t (&sc)[4], f32x2_t (&sh)[4]) {
+            const int c0 = ((xs[j] >> 16) & 0x7fff) - ct * 64;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sc[e] = *reinterpret_cast<const f32x2_t*>(coef + c0 + 2 * e);
+                sh[e] = *reinterpret_cast<const f32x2_t*>(coef + 64 + c0 + 2 * e);
+            }
+            v = *reinterpret_cast<const u32x4_t*>(base + j * 8192);
+        };
+#pragma unroll
+        for (int j = 0; j < 6; j += 2) {
+            const bool second = j < 4 || (wave_s + 8 * 5) * 8 < HROWS;          // uniform
+            u32x4_t v0, v1 = u32x4_t{0u, 0u, 0u, 0u};
+            f32x2_t sc0[4], sh0[4], sc1[4], sh1[4];
+            one(j, v0, sc0, sh0);
+            if (second) one(j + 1, v1, sc1, sh1);
+            v0 = norm_act_piece(v0, sc0, sh0, a.pre_slope, 0u - ((okbits >> j) & 1u));
+            *reinterpret_cast<u32x4_t*>(base + j * 8192) = v0;
+            if (second) {
+                v1 = norm_act_piece(v1, sc1, sh1, a.pre_slope, 0u - ((okbits >> (j + 1)) & 1u));
+                *reinterpret_cast<u32x4_t*>(base + (j + 1) * 8192) = v1;
+            }
         }
     };
 
@@ -151,6 +200,10 @@ wgrad_halo_kernel(WgHaloArgs a, const bf16_t* __restrict__ dy, const bf16_t* __r
     if (tile < a.ntiles) stage(tile, 0);
     for (; tile < a.ntiles; tile += nblk) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PRE) {                              // own slots: this wave's loads have landed, no barrier needed yet
+            normalise(buf, staged_ok);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                     // this patch is in LDS; every wave is done with the other buffer
         if (tile + nblk < a.ntiles) stage(tile + nblk, buf ^ 1);
         s16x4_t ra[4][2], rb[2][2];                        // landing registers of the transposing reads
@@ -284,8 +337,10 @@ int wgrad_halo_slices(const ConvGeom& g) {
     return (int)(ntiles < per ? ntiles : per);
 }
 
-int launch_wgrad_halo(const ConvGeom& g, const void* dy, const void* x, float* parts, float* bias_parts, hipStream_t st) {
+int launch_wgrad_halo(const ConvGeom& g, const void* dy, const void* x, float* parts, float* bias_parts, hipStream_t st,
+                      const float* pre_scale, const float* pre_shift, float pre_slope) {
     WgHaloArgs a;
+    a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_slope = pre_slope;
     int pwl;
     patch_grid(g, &pwl, &a.tiles_w, &a.tiles_h);
     a.B = g.B; a.H = g.H; a.W = g.W;
@@ -295,22 +350,28 @@ int launch_wgrad_halo(const ConvGeom& g, const void* dy, const void* x, float* p
     a.ldc = 9 * g.Cin;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo_kernel<5>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, wgh_lds_bytes(5));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo_kernel<4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, wgh_lds_bytes(4));
+        hipError_t e = hipSuccess;
+        for (const void* k : {reinterpret_cast<const void*>(wgrad_halo_kernel<5, false>), reinterpret_cast<const void*>(wgrad_halo_kernel<5, true>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, wgh_lds_bytes(5));
+        for (const void* k : {reinterpret_cast<const void*>(wgrad_halo_kernel<4, false>), reinterpret_cast<const void*>(wgrad_halo_kernel<4, true>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, wgh_lds_bytes(4));
         if (e != hipSuccess) return fail((int)e, "wgrad_halo: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         configured = true;
     }
     const int blocks = wgrad_halo_slices(g) * a.n_tiles * a.c_tiles;
     const double flops = 2.0 * g.M * g.Cout * 9.0 * g.Cin;
     TimedLaunch timed(TIMED_TN, flops, flops, st);
-    if (pwl == 5)
-        hipLaunchKernelGGL(wgrad_halo_kernel<5>, dim3(blocks), dim3(512), wgh_lds_bytes(5), st, a, (const bf16_t*)dy,
+    if (pwl == 5 && pre_scale)
+        hipLaunchKernelGGL((wgrad_halo_kernel<5, true>), dim3(blocks), dim3(512), wgh_lds_bytes(5), st, a, (const bf16_t*)dy,
+                           (const bf16_t*)x, parts, bias_parts);
+    else if (pwl == 5)
+        hipLaunchKernelGGL((wgrad_halo_kernel<5, false>), dim3(blocks), dim3(512), wgh_lds_bytes(5), st, a, (const bf16_t*)dy,
+                           (const bf16_t*)x, parts, bias_parts);
+    else if (pre_scale)
+        hipLaunchKernelGGL((wgrad_halo_kernel<4, true>), dim3(blocks), dim3(512), wgh_lds_bytes(4), st, a, (const bf16_t*)dy,
                            (const bf16_t*)x, parts, bias_parts);
     else
-        hipLaunchKernelGGL(wgrad_halo_kernel<4>, dim3(blocks), dim3(512), wgh_lds_bytes(4), st, a, (const bf16_t*)dy,
+        hipLaunchKernelGGL((wgrad_halo_kernel<4, false>), dim3(blocks), dim3(512), wgh_lds_bytes(4), st, a, (const bf16_t*)dy,
                            (const bf16_t*)x, parts, bias_parts);
     VAMD_LAUNCH_OK("wgrad_halo");
     return 0;

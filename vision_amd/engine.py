@@ -39,9 +39,17 @@ def _stream():
     return _raw_stream(_cur_device())
 
 
+# a BatchNorm + LeakyReLU in front of a convolution applied inside the convolution's forward and weight-gradient kernels
+# (shapes for which both have a kernel that stages the input patch in LDS): the normalised tensor is never stored.
+# Opt-in: bit-identical, saves one write and two reads of the tensor, but the two kernels are bound by their LDS traffic
+# and the extra pass over the staged patch costs them more than the separate pass takes (64 x 224 x 224 x 64: separate
+# pass 160 us; forward 394 -> 457 us, weight gradient 238 -> 300 us; smaller layers lose 20 - 70 us)
+FUSE_TRAIN_NORM = os.environ.get("VAMD_PRENORM", "0") != "0"
+
+
 class _ShapePlan:
     """What a convolution's launches need to know about one input shape, asked of the library once."""
-    __slots__ = ("d", "ref", "up4_fwd", "parts", "parts_up4", "up4_dgrad", "dgrad_ws", "wgrad_ws", "act_ok", "mfma")
+    __slots__ = ("d", "ref", "up4_fwd", "parts", "parts_up4", "up4_dgrad", "dgrad_ws", "wgrad_ws", "act_ok", "mfma", "prenorm")
 
     def __init__(self, d, has_up4):
         self.d, self.ref = d, C.byref(d)
@@ -52,6 +60,7 @@ class _ShapePlan:
         self.dgrad_ws = lib.vamd_conv2d_dgrad_workspace(self.ref)
         self.wgrad_ws = lib.vamd_conv2d_wgrad_workspace(self.ref)
         self.act_ok = bool(lib.vamd_conv2d_fwd_act_supported(self.ref))
+        self.prenorm = bool(FUSE_TRAIN_NORM and lib.vamd_conv2d_prenorm_supported(self.ref))
         self.mfma = [bool(lib.vamd_conv2d_uses_mfma(self.ref, which)) for which in range(3)]
 
 
@@ -120,10 +129,12 @@ class _Conv:
                      (("fwd", "dgrad", "wgrad")[which], self.cin, self.cout, self.k, self.stride, int(self.up), B, H, W)))
         return e1
 
-    def fwd(self, x, temb=None, res=None, res2=None, bias=True, want_stats=False):
+    def fwd(self, x, temb=None, res=None, res2=None, bias=True, want_stats=False, pre=None):
         """y = conv(x) + bias (+ temb + res + res2).  With want_stats, the kernel's epilogue also
         leaves the per-channel sums of y and y*y (what a train-mode BatchNorm over y needs) in
-        eng.stats_for[y.data_ptr()], if the kernel serving this shape can produce them."""
+        eng.stats_for[y.data_ptr()], if the kernel serving this shape can produce them.
+        pre = (scale, shift, slope): the convolution runs on leaky(x * scale + shift) rounded to the compute dtype, formed
+        inside the kernel (only where plan(...).prenorm says so)."""
         B, H, W, _ = x.shape
         Ho, Wo = self.out_hw(H, W)
         e = self.eng
@@ -132,7 +143,11 @@ class _Conv:
         up4 = sp.up4_fwd
         nparts = (sp.parts_up4 if up4 else sp.parts) if want_stats else 0
         ev = self._timed(0, B, H, W) if e.profile is not None else None
-        if up4:
+        if pre is not None:
+            part = torch.empty((nparts, self.cout, 2), dtype=torch.float32, device=x.device) if nparts > 0 else None
+            call("vamd_conv2d_fwd_prenorm", sp.ref, _ptr(x), _ptr(pre[0]), _ptr(pre[1]), pre[2], _ptr(self.wf),
+                 _ptr(self.b) if bias else None, _ptr(temb), _ptr(res), _ptr(res2), _ptr(y), _ptr(part), _stream())
+        elif up4:
             part = torch.empty((nparts, self.cout, 2), dtype=torch.float32, device=x.device) if nparts > 0 else None
             call("vamd_conv2d_fwd_up4", sp.ref, _ptr(x), _ptr(self.wf4), _ptr(self.b) if bias else None,
                  _ptr(temb), _ptr(res), _ptr(res2), _ptr(y), _ptr(part), _stream())
@@ -215,16 +230,20 @@ class _Conv:
             ev.record()
         return dx
 
-    def wgrad(self, dy, x, bias=True):
+    def wgrad(self, dy, x, bias=True, pre=None):
         """Weight gradient into the arena; with bias=True the bias gradient (column sums of dy)
-        comes out of the same launch."""
+        comes out of the same launch.  pre: as in fwd()."""
         B, H, W, _ = x.shape
         gb = _ptr(self.gb) if bias else None
         ev = self._timed(2, B, H, W)
         sp = self.plan(B, H, W)
         nbytes = sp.wgrad_ws
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-        call("vamd_conv2d_wgrad_oihw", sp.ref, _ptr(dy), _ptr(x), _ptr(self.gw), gb, _ptr(ws), nbytes, _stream())
+        if pre is not None:
+            call("vamd_conv2d_wgrad_prenorm_oihw", sp.ref, _ptr(dy), _ptr(x), _ptr(pre[0]), _ptr(pre[1]), pre[2], _ptr(self.gw),
+                 gb, _ptr(ws), nbytes, _stream())
+        else:
+            call("vamd_conv2d_wgrad_oihw", sp.ref, _ptr(dy), _ptr(x), _ptr(self.gw), gb, _ptr(ws), nbytes, _stream())
         if ev is not None:
             ev.record()
 
@@ -288,7 +307,9 @@ class _Norm:
             self._eval_coef, self._eval_key = coef, key
         return self._eval_coef
 
-    def fwd(self, x, training, mask=None, mask_scale=1.0):
+    def fwd(self, x, training, mask=None, mask_scale=1.0, apply=True):
+        """(normalised + activated x, coefficients).  apply=False: the coefficients alone (the consumer normalises x
+        itself); the first element is then None."""
         B, H, W, Cc = x.shape
         e, dev = self.eng, x.device
         G, R = (1, B * H * W) if self.bn else (B, H * W)
@@ -312,6 +333,8 @@ class _Norm:
             else:
                 call("vamd_gn_finalize", _ptr(part), nchunk, B, Cc, GN_GROUPS, H * W, _ptr(self.gamma),
                      _ptr(self.beta), GN_EPS, _ptr(sc), _ptr(sh), _ptr(mu), _ptr(rs), _stream())
+        if not apply:
+            return None, coef
         y = torch.empty_like(x)
         call("vamd_scale_shift_act", _ptr(x), _ptr(sc), _ptr(sh), _ptr(mask), self.slope, mask_scale, _ptr(y), G, R,
              Cc, e.dt, _stream())
@@ -392,8 +415,12 @@ class _ResBlock:
         fuse = FUSE_EVAL_NORM and not training and tape is None
         a1 = self.eng.act_for.pop(x.data_ptr(), None) if fuse else None   # left by the producer of x, if it could
         coef1 = None
+        B, H, W, _ = x.shape
+        # conv1 / conv2 normalise their input themselves where forward and weight gradient both can (a1 / a2 stay None)
+        pre1 = not fuse and self.conv1.plan(B, H, W).prenorm
+        pre2 = not fuse and not (training and self.spec.dropout > 0.0) and self.conv2.plan(B, H, W).prenorm
         if a1 is None:
-            a1, coef1 = self.bn1.fwd(x, training)
+            a1, coef1 = self.bn1.fwd(x, training, apply=not pre1)
         # projected with the other blocks' in one launch, if this is the embedding that launch projected
         tproj = self.eng.tproj_for.get(id(self)) if (self.temb is not None and self.eng.tproj_src is temb) else None
         if tproj is None and self.temb is not None:
@@ -408,15 +435,21 @@ class _ResBlock:
                 return self.conv2.fwd(a2, res=sc, res2=res2)
             self.eng.act_for[got[1].data_ptr()] = got[0]
             return got[1]
-        h1 = self.conv1.fwd(a1, temb=tproj, want_stats=training)
+        if pre1:
+            h1 = self.conv1.fwd(x, temb=tproj, want_stats=training, pre=(coef1[0], coef1[1], self.bn1.slope))
+        else:
+            h1 = self.conv1.fwd(a1, temb=tproj, want_stats=training)
         mask = None
         if training and self.spec.dropout > 0.0:
             mask = drop_mask if drop_mask is not None else self.eng.draw_dropout(h1.shape, self.spec.dropout)
-        a2, coef2 = self.bn2.fwd(h1, training, mask, self.mask_scale)
+        a2, coef2 = self.bn2.fwd(h1, training, mask, self.mask_scale, apply=not pre2)
         y = None
+        if pre2:
+            sc = self.short.fwd(x) if self.short is not None else x
+            y = self.conv2.fwd(h1, res=sc, res2=res2, want_stats=want_stats, pre=(coef2[0], coef2[1], self.bn2.slope))
         # the 1x1 shortcut as extra reduction steps of conv2: measured +0.3 % on the training step and
         # -2.5 % on 16-image sampling batches against the two-launch form, so it is opt-in
-        if self.short is not None and FUSE_SHORTCUT:
+        if y is None and self.short is not None and FUSE_SHORTCUT:
             y = self.conv2.fwd_short(a2, self.short, x, res2=res2, bias_sum=self.bsum, want_stats=want_stats)
         if y is None:
             sc = self.short.fwd(x) if self.short is not None else x
@@ -430,8 +463,12 @@ class _ResBlock:
         e = self.eng
         # conv2 and shortcut share dy; their bias gradients are the same column sums of dy (copied: letting the shortcut's
         # weight-gradient launch form them again costs more than the copy launch, 19.29 vs 19.17 ms on the 224 x 224 step)
-        self.conv2.wgrad(dy, a2)
-        da2 = self.conv2.dgrad(dy, a2.shape)
+        # a2 is None where conv2 normalises h1 itself (forward above); likewise a1 / x for conv1
+        if a2 is None:
+            self.conv2.wgrad(dy, h1, pre=(coef2[0], coef2[1], self.bn2.slope))
+        else:
+            self.conv2.wgrad(dy, a2)
+        da2 = self.conv2.dgrad(dy, h1.shape)
         dxs = dy
         if self.short is not None:
             self.short.gb.copy_(self.conv2.gb)
@@ -457,8 +494,11 @@ class _ResBlock:
         if training and self._gb_stale:
             self.conv1.gb.zero_()
         self._gb_stale = not training
-        self.conv1.wgrad(dh1, a1, bias=not training)
-        da1 = self.conv1.dgrad(dh1, a1.shape)
+        if a1 is None:
+            self.conv1.wgrad(dh1, x, bias=not training, pre=(coef1[0], coef1[1], self.bn1.slope))
+        else:
+            self.conv1.wgrad(dh1, a1, bias=not training)
+        da1 = self.conv1.dgrad(dh1, x.shape)
         return self.bn1.bwd(da1, x, coef1, None, add=dxs, add2=extra, need_dx=need_dx, training=training)
 
 
