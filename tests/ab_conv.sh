@@ -1,6 +1,9 @@
-# side-by-side microbenchmark of two builds of the library on the same GPU: ab_conv.sh <libB> <cases...>
-LIBB=$1; shift
-for rep in 1 2; do
-  echo "== A (default)"; timeout -k 10 200 python -u tests/perf_conv_gpu.py "$@" 2>&1 | grep -v amdgpu.ids || exit 1
-  echo "== B ($LIBB)"; VAMD_LIB=$LIBB timeout -k 10 200 python -u tests/perf_conv_gpu.py "$@" 2>&1 | grep -v amdgpu.ids || exit 1
+#!/bin/bash
+# Same-box A/B of two builds of the library on single convolution shapes: bash tests/ab_conv.sh "<perf_conv cases>" [PERF_EPI]
+# (base = vision_amd/lib/libvision_amd_base.so, built from an earlier commit by hand; new = the product library)
+CASES=$1; EPI=${2:-0}
+for lib in base new; do
+    L=$PWD/vision_amd/lib/libvision_amd.so; [ $lib = base ] && L=$PWD/vision_amd/lib/libvision_amd_base.so
+    echo "== $lib (PERF_EPI=$EPI)"
+    VAMD_LIB=$L PERF_EPI=$EPI timeout -k 10 200 python tests/perf_conv_gpu.py $CASES || exit 1
 done

@@ -1065,7 +1065,7 @@ struct HaloArgs {
 };
 constexpr int kHaloRows = 344;                             // 10 x 34 = 340 (or 18 x 18 = 324) pixels in whole 8-row pieces
 constexpr int kHaloBuf = kHaloRows * 128;
-constexpr int halo_lds_bytes(int ntaps) { return ntaps * 64 * 128 + 2 * kHaloBuf; }   // resident filter + two patches
+constexpr int halo_lds_bytes(int ntaps) { return ntaps * 64 * 128 + 2 * kHaloBuf + 256; }   // resident filter + two patches + the column tile's bias
 
 template <int EPI, int KR, int KS, bool PRE = false>        // EPI: 0 plain, 1 statistics, 2 fused normalise; PRE: normalise the input
 __global__ void __launch_bounds__(512, 1)
@@ -1103,16 +1103,20 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
             load16_lds(rw, (uint32_t)((n * NTAPS + t) * 64 + chunk * 8) * 2u, true, wt + t * 8192 + wave_s * 1024);
     }
 
+    // the column tile's bias, for the accumulators' start values
+    float* bias_lds = reinterpret_cast<float*>(halo + 2 * kHaloBuf);
+    if (tid < 64) bias_lds[tid] = ep.bias ? ep.bias[n0 + tid] : 0.f;
+    __syncthreads();
+
     // ---- halo staging: wave `wave` copies pieces wave, wave + 8, ... (8 patch pixels x 128 B each)
     constexpr int NPC = (kHaloRows / 8 + 7) / 8;            // 6 pieces per wave
     int h_rc[NPC];                                        // (patch row << 8 | patch column) of this lane's pixel, -1: none
-    int h_chunk[NPC];
+    const int h_chunk = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;   // the same for every piece: (hp & 7) == (lane >> 3) & 7
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
         const int hp = (wave + 8 * j) * 8 + (lane >> 3);
         const int hr = hp / HWd, hc = hp - hr * HWd;
         h_rc[j] = hp < npix ? (hr << 8) | hc : -1;
-        h_chunk[j] = ((lane & 7) ^ (hp & 7)) * 8;
     }
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x);
     uint32_t staged_ok = 0;                               // PRE: bit j = piece j of the patch staged last holds a pixel of the image
@@ -1127,7 +1131,7 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
             if ((wave_s + 8 * j) * 8 >= kHaloRows) continue;               // uniform: no such piece
             const int hi = h0 + (h_rc[j] >> 8), wi = w0 + (h_rc[j] & 255);
             const bool ok = h_rc[j] >= 0 && (unsigned)hi < (unsigned)ha.H && (unsigned)wi < (unsigned)ha.W;
-            const int off = ((b * ha.H + hi) * ha.W + wi) * 64 + h_chunk[j];
+            const int off = ((b * ha.H + hi) * ha.W + wi) * 64 + h_chunk;
             load16_lds(rx, (uint32_t)off * 2u, ok, halo + buf * kHaloBuf + (wave_s + 8 * j) * 1024);
             if constexpr (PRE) staged_ok |= ok ? 1u << j : 0u;
         }
@@ -1137,7 +1141,7 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
     // sixteen coefficients stay in registers; slots of padding pixels keep the zeros the hardware wrote.
     f32x2_t psc[4], psh[4];
     if constexpr (PRE) {
-        const int c0 = h_chunk[0];
+        const int c0 = h_chunk;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             psc[e] = *reinterpret_cast<const f32x2_t*>(ep.pre_scale + c0 + 2 * e);
@@ -1176,16 +1180,16 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
     float s1[STATS ? CPL : 1], s2[STATS ? CPL : 1];
 #pragma unroll
     for (int e = 0; e < (STATS ? CPL : 1); ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    // Accumulators start from the bias (as in the other kernels: the same order of additions, bit for bit), read from
+    // LDS: an accumulator that starts from a value loaded from memory makes the first MFMA of every tile wait for that
+    // load, and since the compiler cannot count past the direct-to-LDS loads issued just before, it waits with vmcnt(0)
+    // -- the NEXT patch's loads would have to land before this tile's MFMAs may start.
     auto init_acc = [&]() {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (ep.bias) {
-                const float4 t4 = *reinterpret_cast<const float4*>(ep.bias + nb + 4 * j);
-                bv = f32x4_t{t4.x, t4.y, t4.z, t4.w};
-            }
+            const float4 t4 = *reinterpret_cast<const float4*>(bias_lds + nb - n0 + 4 * j);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = bv;
+            for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{t4.x, t4.y, t4.z, t4.w};
         }
     };
 
@@ -1194,8 +1198,13 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
     int buf = 0;
     if (tile < ha.ntiles) stage(tile, 0);
     init_acc();
+    // Waits on vmcnt are written as the builtin, which the compiler's own wait insertion sees (vmcnt(0), other counters
+    // untouched): behind an asm wait it takes earlier loads for pending and orders the direct-to-LDS loads of a patch behind
+    // them one by one.  A patch is waited for BEFORE the epilogue of the tile in front of it (its loads are a whole tap
+    // loop old by then), not at the top of its own tile: there the wait would also cover that epilogue's stores, and
+    // every tile would stand still for a store's round trip to L2.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (; tile < ha.ntiles; tile += nblk) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (PRE) {                              // own slots: this wave's loads have landed, no barrier needed yet
             normalise(buf, staged_ok);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1203,7 +1212,7 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
         __builtin_amdgcn_s_barrier();                     // this tile's patch (and the filter) is in LDS; every wave is past the previous tile
         if (tile + nblk < ha.ntiles) stage(tile + nblk, buf ^ 1);
         // ---- this tile's rows, and its epilogue operands: loaded now, used after the 144 MFMAs
-        int64_t offs[4];
+        uint32_t offs[4];                                 // element offsets: outputs are below 2 GiB (checked on the host)
         bool valid[4];
         int img;
         {
@@ -1215,8 +1224,8 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
                 const int q = wm * 64 + i * 16 + frow;
                 const int h = ty * PH + (q >> ha.pw_log2), wq = tx * PW + (q & (PW - 1));
                 valid[i] = h < ha.H && wq < ha.W;
-                offs[i] = ha.ostep ? (((int64_t)img * 2 * ha.H + 2 * h + ph) * 2 * ha.W + 2 * wq + pw) * N + nb
-                                   : (((int64_t)img * ha.H + h) * ha.W + wq) * N + nb;
+                offs[i] = ha.ostep ? (uint32_t)(((img * 2 * ha.H + 2 * h + ph) * 2 * ha.W + 2 * wq + pw) * N + nb)
+                                   : (uint32_t)(((img * ha.H + h) * ha.W + wq) * N + nb);
             }
         }
         float tv[CPL];
@@ -1229,19 +1238,32 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
         }
         const T* r1 = reinterpret_cast<const T*>(ep.res ? ep.res : ep.res2);
         const T* r2 = reinterpret_cast<const T*>(ep.res ? ep.res2 : nullptr);
-        Vec16<T> rv[4];
-        if (r1) {
+        Vec16<T> rv[4], rw[4];                             // both terms before the epilogue: a load issued between its stores would
+        if (r1) {                                         // have to wait for the stores before it
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (valid[i]) rv[i] = *reinterpret_cast<const Vec16<T>*>(r1 + offs[i]);
         }
+        if (r2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (valid[i]) rw[i] = *reinterpret_cast<const Vec16<T>*>(r2 + offs[i]);
+        }
+
         const unsigned char* sa = halo + buf * kHaloBuf;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
             const int toff = (ph + t / KS) * HWd + pw + (t % KS);
+            // The fragment addresses of all nine taps are the same for every tile; hoisted out of the tile loop they would
+            // take 72 registers, which this kernel does not have (the epilogue's operands would be spilled): hp0 passes through
+            // an empty asm once per tap, so the addresses are formed where they are used (three vector instructions a read).
             int arow[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) arow[i] = hp0[i] + toff;
+            for (int i = 0; i < 4; ++i) {
+                int h = hp0[i];
+                asm volatile("" : "+v"(h));
+                arow[i] = h + toff;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 Frag a[4], b[NT];
@@ -1260,6 +1282,7 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
             }
         }
         // ---- epilogue of this tile: y = acc + temb + res + res2 (in this order), rounded, stored, summed
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // the next patch and this tile's terms have landed; no store is pending yet
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (!valid[i]) continue;
@@ -1271,9 +1294,8 @@ conv_c64_halo_kernel(HaloArgs ha, const bf16_t* __restrict__ x, const bf16_t* __
                 for (int e = 0; e < CPL; ++e) v[e] += to_f(rv[i].v[e]);
             }
             if (r2) {
-                const Vec16<T> q2 = *reinterpret_cast<const Vec16<T>*>(r2 + offs[i]);
 #pragma unroll
-                for (int e = 0; e < CPL; ++e) v[e] += to_f(q2.v[e]);
+                for (int e = 0; e < CPL; ++e) v[e] += to_f(rw[i].v[e]);
             }
             Vec16<T> ov;
 #pragma unroll
