@@ -156,6 +156,12 @@ int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, fl
 int vamd_conv2d_wgrad_oihw(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
                            void* workspace, size_t workspace_bytes, void* stream);
 size_t vamd_conv2d_wgrad_workspace(const vamd_conv_desc* d);
+/* vamd_conv2d_wgrad_oihw for a 1x1 convolution that is THREE convolutions side by side (Cout = 3 * C3, output channels
+ * [j*C3, (j+1)*C3) belong to convolution j: the q_proj / k_proj / v_proj of AttnBlock, reference models/ddpm.py:95-97,
+ * applied to the same normalised input in one launch): gradient rows and bias sums of convolution j are written to
+ * dw[j] ([C3][Cin] fp32) and dbias[j] ([C3], or dbias == NULL), i.e. straight into three separate parameters' .grad. */
+int vamd_conv2d_wgrad_oihw_split3(const vamd_conv_desc* d, const void* dy, const void* x, float* const dw[3],
+                                  float* const dbias[3], void* workspace, size_t workspace_bytes, void* stream);
 
 /* Convolution whose INPUT is BatchNorm2d + LeakyReLU of a stored tensor x (training or eval mode), with that
  * normalisation applied INSIDE the kernels: reference models/ddpm.py:49-60, `self.block1 = Sequential(BatchNorm2d, act,
@@ -201,7 +207,11 @@ typedef struct vamd_repack_item {
     void* w_fwd;           /* [Cout][k][k][Cin] in dtype */
     void* w_dgrad;         /* [Cin][k][k][Cout] flipped, or NULL */
     long long first_block;
-    int Cout, Cin, ksize, reserved;
+    int Cout, Cin, ksize;
+    int ld_dgrad;          /* elements between consecutive [Cin][k][k] rows of w_dgrad; 0 = Cout.  Larger when the item's
+                            * output channels are a column range of a wider filter (q / k / v projections side by side) */
+    const float* bias;     /* with bias_out != NULL: bias_out[0 .. Cout) = bias[0 .. Cout) in the same launch */
+    float* bias_out;
 } vamd_repack_item;
 int vamd_repack_weights(const vamd_repack_item* items, int n, long long total_blocks, int dtype, void* stream);
 /* fp32 [Cout][k][k][Cin] -> fp32 [Cout][Cin][k][k] (gradient back to torch layout). */
@@ -320,6 +330,9 @@ int vamd_unpool2x2(const void* x, const void* add, void* y, int B, int Hs, int W
                    void* stream);
 /* x [batch][R][C] -> y [batch][C][ldy] (ldy >= R; padding columns are left untouched). */
 int vamd_transpose(const void* x, void* y, int batch, int R, int C, int ldy, int dtype, void* stream);
+/* The same for an x whose rows are ldx >= C elements apart (batch z starts at z*R*ldx): a column range of a wider
+ * tensor, such as k or v inside the output [B][S][3C] of the fused q / k / v projection. */
+int vamd_transpose_ld(const void* x, void* y, int batch, int R, int C, int ldx, int ldy, int dtype, void* stream);
 /* The attention core of AttnBlock.forward (reference models/ddpm.py:113-120) in one kernel, bf16: o = softmax(q k^T *
  * scale) v per image; q, k: [B][S][C]; vT: the values transposed, [B][C][ldv] (ldv >= S, a multiple of 8; columns past
  * S are not read); o: [B][S][C].  S <= 1024, C a multiple of 32 up to 512 (vamd_attention_fwd_supported).  The S x S

@@ -852,6 +852,82 @@ def test_repack_weights_batched_matches_single(dts):
         assert torch.equal(wf.float(), w.permute(0, 2, 3, 1).to(tdt).float())
 
 
+@pytest.mark.parametrize("dts", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 18, 18, 256), (3, 14, 14, 512), (2, 9, 11, 64)], ids=lambda s: "x".join(map(str, s)))
+def test_three_projections_as_one_convolution(shape, dts):
+    """The pieces the fused q / k / v projection of an attention block is made of: the weight re-pack writing three
+    filters' input-gradient forms side by side (ld_dgrad) and their biases into one vector, the forward / input gradient
+    of the 3C-wide 1x1 convolution against the three separate ones, the weight gradient split over three destinations
+    (vamd_conv2d_wgrad_oihw_split3) against three separate calls, and the transpose of a channel range (vamd_transpose_ld)."""
+    from vision_amd._lib import RepackItem
+    B, H, W, Cc = shape
+    tdt, dt = DT[dts]
+    gen = torch.Generator().manual_seed(sum(shape))
+    ws = [(torch.randn((Cc, Cc, 1, 1), generator=gen) / math.sqrt(Cc)).to(DEV) for _ in range(3)]
+    bs = [torch.randn(Cc, generator=gen).to(DEV) for _ in range(3)]
+    wf3 = torch.full((3 * Cc, 1, 1, Cc), 7.0, dtype=tdt, device=DEV)
+    wd3 = torch.full((Cc, 1, 1, 3 * Cc), 7.0, dtype=tdt, device=DEV)
+    b3 = torch.full((3 * Cc,), 7.0, device=DEV)
+    singles = []
+    items, blocks = (RepackItem * 3)(), 0
+    for j, (it, w, b) in enumerate(zip(items, ws, bs)):
+        wf1 = torch.empty((Cc, 1, 1, Cc), dtype=tdt, device=DEV)
+        wd1 = torch.empty((Cc, 1, 1, Cc), dtype=tdt, device=DEV)
+        call("vamd_repack_weight", P(w), P(wf1), P(wd1), Cc, Cc, 1, dt, S())
+        singles.append((wf1, wd1))
+        it.w, it.w_fwd = w.data_ptr(), wf3.data_ptr() + j * Cc * Cc * wf3.element_size()
+        it.w_dgrad, it.ld_dgrad = wd3.data_ptr() + j * Cc * wd3.element_size(), 3 * Cc
+        it.first_block, it.Cout, it.Cin, it.ksize = blocks, Cc, Cc, 1
+        it.bias, it.bias_out = b.data_ptr(), b3.data_ptr() + j * Cc * 4
+        blocks += ((Cc + 31) // 32) ** 2
+    table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(DEV)
+    call("vamd_repack_weights", P(table), 3, blocks, dt, S())
+    assert torch.equal(wf3, torch.cat([wf1 for wf1, _ in singles], 0))
+    assert torch.equal(wd3, torch.cat([wd1 for _, wd1 in singles], 3))
+    assert torch.equal(b3, torch.cat(bs))
+    # forward: one convolution over 3C output channels = the three side by side
+    x, _ = rnd((B, H, W, Cc), tdt, gen)
+    d1 = ConvDesc(B, H, W, Cc, Cc, 1, 1, 0, 0, dt, _lib.ALGO_AUTO)
+    d3 = ConvDesc(B, H, W, Cc, 3 * Cc, 1, 1, 0, 0, dt, _lib.ALGO_AUTO)
+    y3 = torch.empty((B, H, W, 3 * Cc), dtype=tdt, device=DEV)
+    call("vamd_conv2d_fwd", C.byref(d3), P(x), P(wf3), P(b3), None, None, None, P(y3), S())
+    for j in range(3):
+        y1 = torch.empty((B, H, W, Cc), dtype=tdt, device=DEV)
+        call("vamd_conv2d_fwd", C.byref(d1), P(x), P(singles[j][0]), P(bs[j]), None, None, None, P(y1), S())
+        assert relerr(y3[..., j * Cc:(j + 1) * Cc], y1) < (1e-6 if dts == "f32" else 1e-2)
+    # the transpose of a channel range
+    S_, Sp = H * W, (H * W + 7) // 8 * 8
+    vT = torch.zeros((B, Cc, Sp), dtype=tdt, device=DEV)
+    call("vamd_transpose_ld", P(y3[..., 2 * Cc:]), P(vT), B, S_, Cc, 3 * Cc, Sp, dt, S())
+    assert torch.equal(vT[:, :, :S_], y3[..., 2 * Cc:].reshape(B, S_, Cc).transpose(1, 2))
+    # input gradient of the wide convolution = the sum of the three
+    dy3, dy64 = rnd((B, H, W, 3 * Cc), tdt, gen)
+    dx3 = torch.empty((B, H, W, Cc), dtype=tdt, device=DEV)
+    nb = lib.vamd_conv2d_dgrad_workspace(C.byref(d3))
+    ws_ = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    call("vamd_conv2d_dgrad", C.byref(d3), P(dy3), P(wd3), None, P(dx3), P(ws_), nb, S())
+    ref = sum(dy64[..., j * Cc:(j + 1) * Cc].reshape(-1, Cc) @ singles[j][0].double().cpu().reshape(Cc, Cc) for j in range(3))
+    assert relerr(dx3.reshape(-1, Cc), ref) < TOL_OUT[dts]
+    # weight gradient into three destinations = three separate weight gradients, bit for bit
+    if not lib.vamd_conv2d_uses_mfma(C.byref(d3), 2):
+        pytest.skip("shape outside the MFMA weight-gradient kernel")
+    nb3 = lib.vamd_conv2d_wgrad_workspace(C.byref(d3))
+    w3 = torch.empty(max(nb3, 16), dtype=torch.uint8, device=DEV)
+    gw = [torch.full((Cc, Cc, 1, 1), 7.0, device=DEV) for _ in range(3)]
+    gb = [torch.full((Cc,), 7.0, device=DEV) for _ in range(3)]
+    call("vamd_conv2d_wgrad_oihw_split3", C.byref(d3), P(dy3), P(x), C.byref((C.c_void_p * 3)(*[P(t) for t in gw])),
+         C.byref((C.c_void_p * 3)(*[P(t) for t in gb])), P(w3), nb3, S())
+    x64 = x.double().cpu().reshape(-1, Cc)
+    for j in range(3):
+        g64 = dy64[..., j * Cc:(j + 1) * Cc].reshape(-1, Cc).T @ x64
+        assert relerr(gw[j].reshape(Cc, Cc), g64) < TOL_F32OUT[dts]
+        assert relerr(gb[j], dy64[..., j * Cc:(j + 1) * Cc].reshape(-1, Cc).sum(0)) < TOL_F32OUT[dts]
+    gw2 = [torch.full((Cc, Cc, 1, 1), 3.0, device=DEV) for _ in range(3)]
+    call("vamd_conv2d_wgrad_oihw_split3", C.byref(d3), P(dy3), P(x), C.byref((C.c_void_p * 3)(*[P(t) for t in gw2])), None,
+         P(w3), nb3, S())
+    assert all(torch.equal(a, b) for a, b in zip(gw, gw2))
+
+
 def test_linear_fwd_multi_matches_single():
     """Several linear layers over one input in one launch = the same layers one by one."""
     from vision_amd._lib import LinearItem

@@ -49,7 +49,8 @@ CONV_SCRATCH_BYTES = 4096 + 256 * 256 * 256 * 4      # VAMD_CONV_SCRATCH_BYTES
 
 class RepackItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p), ("first_block", C.c_longlong),
-                ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("reserved", C.c_int32)]
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("ld_dgrad", C.c_int32),
+                ("bias", C.c_void_p), ("bias_out", C.c_void_p)]
 
 
 class LinearItem(C.Structure):
@@ -97,6 +98,7 @@ SIGNATURES = {
     "vamd_conv2d_wgrad": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
     "vamd_conv2d_wgrad_oihw": (_i, [_d, _p, _p, _p, _p, _p, _z, _p]),
     "vamd_conv2d_wgrad_workspace": (_z, [_d]),
+    "vamd_conv2d_wgrad_oihw_split3": (_i, [_d, _p, _p, C.POINTER(C.c_void_p * 3), C.POINTER(C.c_void_p * 3), _p, _z, _p]),
     "vamd_conv2d_prenorm_supported": (_i, [_d]),
     "vamd_conv2d_fwd_prenorm": (_i, [_d, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vamd_conv2d_wgrad_prenorm_oihw": (_i, [_d, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p]),
@@ -124,6 +126,7 @@ SIGNATURES = {
     "vamd_pool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "vamd_unpool2x2": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "vamd_transpose": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vamd_transpose_ld": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vamd_attention_fwd_supported": (_i, [_i, _i, _i]),
     "vamd_attention_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "vamd_softmax_rows": (_i, [_p, _p, _l, _i, _i, _i, _p]),

@@ -362,6 +362,24 @@ static int conv2d_wgrad_impl(const char* who, const vamd_conv_desc* d, const voi
     return vamd_unpack_wgrad(out, dw, g.Cout, g.Cin, g.k, stream);
 }
 
+int vamd_conv2d_wgrad_oihw_split3(const vamd_conv_desc* d, const void* dy, const void* x, float* const dw[3],
+                                  float* const dbias[3], void* workspace, size_t workspace_bytes, void* stream) {
+    const char* who = "vamd_conv2d_wgrad_oihw_split3";
+    ConvGeom g;
+    int rc = conv_geom(d, &g, who);
+    if (rc) return rc;
+    VAMD_REQUIRE(dy && x && dw && dw[0] && dw[1] && dw[2], "%s: null tensor", who);
+    VAMD_REQUIRE(!dbias || (dbias[0] && dbias[1] && dbias[2]), "%s: null bias gradient", who);
+    VAMD_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dw[0] % 16 == 0 && (uintptr_t)dw[1] % 16 == 0 &&
+                 (uintptr_t)dw[2] % 16 == 0 && (uintptr_t)workspace % 16 == 0, "%s: tensors must be 16-byte aligned", who);
+    VAMD_REQUIRE(g.k == 1 && g.Cout % 3 == 0 && g.Cin % 4 == 0, "%s: needs a 1x1 filter, Cout a multiple of 3 and Cin of 4", who);
+    const int a = pick(d->algo, conv_wgrad_thin_supported(g, d->dtype), conv_wgrad_mfma_supported(g, d->dtype), who, g);
+    if (a < 0) return a;
+    if (a != kMfma) return fail(VAMD_EUNSUPPORTED, "%s: needs the MFMA weight-gradient kernel (Cin=%d Cout=%d)", who, g.Cin, g.Cout);
+    return conv_wgrad_mfma(g, d->dtype, dy, x, nullptr, nullptr, 1, workspace, workspace_bytes, as_stream(stream), nullptr, nullptr,
+                           0.f, dw, dbias);
+}
+
 int vamd_conv2d_wgrad(const vamd_conv_desc* d, const void* dy, const void* x, float* dw, float* dbias,
                       void* workspace, size_t workspace_bytes, void* stream) {
     return conv2d_wgrad_impl("vamd_conv2d_wgrad", d, dy, x, dw, dbias, 0, workspace, workspace_bytes, stream);

@@ -2633,6 +2633,14 @@ static int tn_wgrad_slices(const ConvGeom& g, int dtype) {
     return slices;
 }
 
+// split_rows > 0 (1x1 filters only): output rows [j * split_rows, (j + 1) * split_rows) go to dw[j] / dbias[j] instead of
+// one tensor -- three projections computed as one convolution, each with its own parameter
+struct WgradSplit {
+    int split_rows;
+    float* dw[2];          // destinations of the second and third row range (the first is the kernel's dw)
+    float* dbias[2];
+};
+
 // Sums the slices' partial products and writes the gradient either as [Cout][k][k][Cin] or in
 // torch's [Cout][Cin][k][k].  A block covers 256/SL groups of 4 consecutive filter columns with SL
 // slice lanes each (SL = 32 when there are many slices and few outputs); the blocks after those
@@ -2640,7 +2648,7 @@ static int tn_wgrad_slices(const ConvGeom& g, int dtype) {
 template <int SL>
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ parts, const float* __restrict__ bias_parts, int slices, int N, int Ktot,
-                    int Cin, int k, int oihw, float* __restrict__ dw, float* __restrict__ dbias) {
+                    int Cin, int k, int oihw, float* __restrict__ dw, float* __restrict__ dbias, WgradSplit sp) {
     constexpr int OG = 256 / SL;
     __shared__ float4 red[SL][OG];
     const int tx = threadIdx.x % OG, ty = threadIdx.x / OG;
@@ -2657,7 +2665,12 @@ wgrad_reduce_kernel(const float* __restrict__ parts, const float* __restrict__ b
             float tot = 0.f;
 #pragma unroll
             for (int i = 0; i < 32; ++i) tot += redf[i * 8 + (threadIdx.x & 7)];
-            dbias[n] = tot;
+            if (sp.split_rows > 0 && n >= sp.split_rows) {
+                const int j = n / sp.split_rows;
+                sp.dbias[j - 1][n - j * sp.split_rows] = tot;
+            } else {
+                dbias[n] = tot;
+            }
         }
         return;
     }
@@ -2691,6 +2704,14 @@ wgrad_reduce_kernel(const float* __restrict__ parts, const float* __restrict__ b
         r4.x += v.x; r4.y += v.y; r4.z += v.z; r4.w += v.w;
     }
     if (!oihw || k == 1) {
+        if (sp.split_rows > 0) {                          // Ktot % 4 == 0: a group of four stays inside one row
+            const int64_t per = (int64_t)sp.split_rows * Ktot / 4;
+            const int j = (int)(q / per);
+            if (j > 0) {
+                reinterpret_cast<float4*>(sp.dw[j - 1])[q - j * per] = r4;
+                return;
+            }
+        }
         reinterpret_cast<float4*>(dw)[q] = r4;
         return;
     }
@@ -2758,7 +2779,14 @@ size_t conv_wgrad_mfma_workspace(const ConvGeom& g, int dtype) {
 
 int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
                     int oihw, void* workspace, size_t workspace_bytes, hipStream_t st, const float* pre_scale,
-                    const float* pre_shift, float pre_slope) {
+                    const float* pre_shift, float pre_slope, float* const* dw3, float* const* dbias3) {
+    WgradSplit sp{0, {nullptr, nullptr}, {nullptr, nullptr}};
+    if (dw3) {
+        if (g.k != 1 || g.Cout % 3 != 0) return fail(VAMD_EINVAL, "conv_wgrad_mfma: three-way split needs a 1x1 filter and Cout % 3 == 0");
+        sp.split_rows = g.Cout / 3;
+        dw = dw3[0]; sp.dw[0] = dw3[1]; sp.dw[1] = dw3[2];
+        if (dbias3) { dbias = dbias3[0]; sp.dbias[0] = dbias3[1]; sp.dbias[1] = dbias3[2]; }
+    }
     Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
     if (!workspace || workspace_bytes < conv_wgrad_mfma_workspace(g, dtype))
         return fail(VAMD_EINVAL, "conv_wgrad_mfma: needs %zu workspace bytes", conv_wgrad_mfma_workspace(g, dtype));
@@ -2780,10 +2808,10 @@ int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x,
     const unsigned bias_blocks = dbias ? (unsigned)((g.Cout + 7) / 8) : 0u;
     if (slices >= 32)
         hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((unsigned)((total4 + 7) / 8) + bias_blocks), dim3(256), 0, st, parts,
-                           bias_parts, slices, g.Cout, gp.Ktot, g.Cin, g.k, oihw, dw, dbias);
+                           bias_parts, slices, g.Cout, gp.Ktot, g.Cin, g.k, oihw, dw, dbias, sp);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total4 + 63) / 64) + bias_blocks), dim3(256), 0, st, parts,
-                           bias_parts, slices, g.Cout, gp.Ktot, g.Cin, g.k, oihw, dw, dbias);
+                           bias_parts, slices, g.Cout, gp.Ktot, g.Cin, g.k, oihw, dw, dbias, sp);
     VAMD_LAUNCH_OK("wgrad_reduce");
     return 0;
 }
@@ -2871,10 +2899,10 @@ int conv_wgrad_up4_mfma(const ConvGeom& g, int dtype, const void* dy, const void
     const int64_t total4 = (int64_t)dgn / 4;
     if (slices >= 32)
         hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((unsigned)((total4 + 7) / 8)), dim3(256), 0, st, parts, nullptr, slices,
-                           g.Cin, F, g.Cout, 1, 0, dg, nullptr);
+                           g.Cin, F, g.Cout, 1, 0, dg, nullptr, WgradSplit{0, {nullptr, nullptr}, {nullptr, nullptr}});
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, parts, nullptr, slices,
-                           g.Cin, F, g.Cout, 1, 0, dg, nullptr);
+                           g.Cin, F, g.Cout, 1, 0, dg, nullptr, WgradSplit{0, {nullptr, nullptr}, {nullptr, nullptr}});
     VAMD_LAUNCH_OK("wgrad_reduce");
     hipLaunchKernelGGL(wgrad_up4_fold_kernel, dim3((unsigned)(((int64_t)g.Cin * g.Cout + 255) / 256)), dim3(256), 0, st, dg,
                        bias_parts, slices, g.Cin, g.Cout, oihw, dw, dbias);

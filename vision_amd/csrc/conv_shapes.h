@@ -83,7 +83,8 @@ bool conv_wgrad_mfma_supported(const ConvGeom& g, int dtype);
 size_t conv_wgrad_mfma_workspace(const ConvGeom& g, int dtype);
 int conv_wgrad_mfma(const ConvGeom& g, int dtype, const void* dy, const void* x, float* dw, float* dbias,
                     int oihw, void* workspace, size_t workspace_bytes, hipStream_t st, const float* pre_scale = nullptr,
-                    const float* pre_shift = nullptr, float pre_slope = 0.f);
+                    const float* pre_shift = nullptr, float pre_slope = 0.f, float* const* dw3 = nullptr,
+                    float* const* dbias3 = nullptr);
 // input = BatchNorm + LeakyReLU of a stored tensor, applied inside the forward and weight-gradient kernels
 bool conv_prenorm_mfma_supported(const ConvGeom& g, int dtype);
 int conv_fwd_prenorm_mfma(const ConvGeom& g, int dtype, const void* x, const float* pre_scale, const float* pre_shift,

@@ -293,17 +293,17 @@ __global__ void convert_transpose_kernel(const TIn* __restrict__ x, TOut* __rest
     }
 }
 
-// [batch][R][C] -> [batch][C][R], 32x32 tiles through LDS (+1 pad).
+// [batch][R][C] (rows ldx elements apart) -> [batch][C][R] (rows ldy apart), 32x32 tiles through LDS (+1 pad).
 template <typename T>
-__global__ void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int C, int ldy) {
+__global__ void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int C, int ldx, int ldy) {
     __shared__ float tile[32][33];
-    const int64_t base = (int64_t)blockIdx.z * R * C;
+    const int64_t base = (int64_t)blockIdx.z * R * ldx;
     const int64_t obase = (int64_t)blockIdx.z * C * ldy;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
     for (int i = ty; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + tx;
-        if (r < R && c < C) tile[i][tx] = to_f(x[base + (int64_t)r * C + c]);
+        if (r < R && c < C) tile[i][tx] = to_f(x[base + (int64_t)r * ldx + c]);
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
@@ -648,10 +648,13 @@ repack_weights_kernel(const vamd_repack_item* __restrict__ items, int n) {
     }
     const vamd_repack_item it = items[lo];
     const int O = it.Cout, I = it.Cin, k = it.ksize, kk = k * k;
+    const int LD = it.ld_dgrad > 0 ? it.ld_dgrad : O;         // elements between the rows [i][tap] of w_dgrad
     const float* __restrict__ w = it.w;
     T* __restrict__ wf = (T*)it.w_fwd;
     T* __restrict__ wd = (T*)it.w_dgrad;
     const int local = (int)((long long)blockIdx.x - it.first_block);
+    if (local == 0 && it.bias_out)                           // the bias rides along (a fused projection's concatenated bias)
+        for (int n = threadIdx.x; n < O; n += 256) it.bias_out[n] = it.bias[n];
     const int i_tiles = (I + TI - 1) / TI;
     const int o0 = (local / i_tiles) * TO, i0 = (local % i_tiles) * TI;
     const int run = TI * kk;                                 // source floats per output channel in this tile
@@ -688,7 +691,7 @@ repack_weights_kernel(const vamd_repack_item* __restrict__ items, int n) {
             const int o = o0 + ol, i = i0 + il;
             if (o < O && i < I) {
                 T two[2] = {from_f<T>(tile[ol][il * kk + tap]), from_f<T>(tile[ol + 1][il * kk + tap])};
-                T* dst = wd + ((int64_t)i * kk + (kk - 1 - tap)) * O + o;
+                T* dst = wd + ((int64_t)i * kk + (kk - 1 - tap)) * LD + o;
                 if (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(two);
                 else *reinterpret_cast<uint64_t*>(dst) = *reinterpret_cast<const uint64_t*>(two);
             }
@@ -697,7 +700,7 @@ repack_weights_kernel(const vamd_repack_item* __restrict__ items, int n) {
         for (int idx = threadIdx.x; idx < TO * run; idx += 256) {      // wd[i][flipped tap][o]
             const int ol = idx % TO, tap = (idx / TO) % kk, il = idx / (TO * kk);
             const int o = o0 + ol, i = i0 + il;
-            if (o < O && i < I) wd[((int64_t)i * kk + (kk - 1 - tap)) * O + o] = from_f<T>(tile[ol][il * kk + tap]);
+            if (o < O && i < I) wd[((int64_t)i * kk + (kk - 1 - tap)) * LD + o] = from_f<T>(tile[ol][il * kk + tap]);
         }
     }
 }
@@ -902,7 +905,12 @@ int vamd_qsample(const float* x0, const float* eps, const float* t, void* xt, fl
     return 0;
 }
 
-int vamd_l1_chunks(int64_t npix) { return grid_for(npix, 256, 1024); }
+// at least one workgroup per CU: a many-channel tensor (a latent: 256 channels on 7 x 7 pixels) has few pixels and
+// many work items per pixel, and 13 workgroups walked its 0.8 M elements in 139 us
+int vamd_l1_chunks(int64_t npix) {
+    const int n = grid_for(npix, 256, 1024);
+    return n < 256 ? 256 : n;
+}
 
 int vamd_l1_loss_fwd(const void* pred, const float* eps, float* partial, float* loss, int B, int C,
                      int H, int W, int dtype, void* stream) {
@@ -1037,16 +1045,20 @@ int vamd_add_cast(const void* a, int a_dtype, const void* b, int b_dtype, void* 
     return 0;
 }
 
-int vamd_transpose(const void* x, void* y, int batch, int R, int C, int ldy, int dtype, void* stream) {
-    VAMD_REQUIRE(x && y && batch > 0 && R > 0 && C > 0 && ldy >= R, "vamd_transpose: bad argument");
+int vamd_transpose_ld(const void* x, void* y, int batch, int R, int C, int ldx, int ldy, int dtype, void* stream) {
+    VAMD_REQUIRE(x && y && batch > 0 && R > 0 && C > 0 && ldx >= C && ldy >= R, "vamd_transpose: bad argument");
     VAMD_REQUIRE(batch <= 65535 && (R + 31) / 32 <= 65535, "vamd_transpose: grid too large");
     dim3 grid((C + 31) / 32, (R + 31) / 32, batch);
     VAMD_DISPATCH(dtype, "vamd_transpose", {
         hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, as_stream(stream), (const T*)x,
-                           (T*)y, R, C, ldy);
+                           (T*)y, R, C, ldx, ldy);
     });
     VAMD_LAUNCH_OK("vamd_transpose");
     return 0;
+}
+
+int vamd_transpose(const void* x, void* y, int batch, int R, int C, int ldy, int dtype, void* stream) {
+    return vamd_transpose_ld(x, y, batch, R, C, C, ldy, dtype, stream);
 }
 
 int vamd_softmax_rows(const float* x, void* y, int64_t rows, int cols, int ld, int dtype, void* stream) {

@@ -247,65 +247,64 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nc
 // BatchNorm backward from per-image partial sums [B][nchunk][C][3] = (gz, gz*xhat, xhat): the usual
 // coefficients and parameter gradients from the totals, and, because dx = cA*gz + cC*xhat + cB is
 // affine in the summed quantities, the per-image channel sums of dx (the gradient of a per-image,
-// per-channel additive term of the normalised tensor's producer) and their total.  One wave per
-// channel, lane = image (strided), fixed order of additions.
-__global__ void bn_bwd_finalize_img_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
-                                           double hw, const float* __restrict__ scale, float* dgamma,
-                                           float* dbeta, float* cA, float* cB, float* cC,
-                                           float* __restrict__ dsum, float* __restrict__ dsum_total,
-                                           int fixed_stats) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    // totals over every (image, chunk) pair, pairs dealt to the lanes
-    double t1 = 0.0, t2 = 0.0;
+// per-channel additive term of the normalised tensor's producer) and their total.  One workgroup of four
+// waves per channel.  An image's chunks are shared by L = min(64, largest power of two <= nchunk) lanes of
+// one wave and 256 / L images are in flight at a time; every sum has a fixed order of additions.
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_img_kernel(const float* __restrict__ partial, int nchunk, int B, int C,
+                           double hw, const float* __restrict__ scale, float* dgamma,
+                           float* dbeta, float* cA, float* cB, float* cC,
+                           float* __restrict__ dsum, float* __restrict__ dsum_total,
+                           int fixed_stats) {
+    __shared__ double red[4][3];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // totals over every (image, chunk) pair, pairs dealt to the threads
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
     const int pairs = B * nchunk;
-    for (int i = lane; i < pairs; i += 64) {
+    for (int i = tid; i < pairs; i += 256) {
         const float* q = partial + ((int64_t)i * C + c) * 3;
         t1 += (double)q[0];
         t2 += (double)q[1];
+        t3 += (double)q[2];
     }
-    const double s1 = wave_sum_d(t1), s2 = wave_sum_d(t2);
+    t1 = wave_sum_d(t1);
+    t2 = wave_sum_d(t2);
+    t3 = wave_sum_d(t3);
+    if (lane == 0) { red[wave][0] = t1; red[wave][1] = t2; red[wave][2] = t3; }
+    __syncthreads();
+    const double s1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    const double s2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    const double s3 = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
     const double count = hw * B;
     const double sc = (double)scale[c];
     const double a = sc, bq = fixed_stats ? 0.0 : -sc * s1 / count, cq = fixed_stats ? 0.0 : -sc * s2 / count;
-    double tot = 0.0;
-    if (nchunk >= 16) {
-        // few images with many chunks each (large feature maps): the lanes share one image's chunks
-        for (int b = 0; b < B; ++b) {
-            double g1 = 0.0, g3 = 0.0;
-            for (int k = lane; k < nchunk; k += 64) {
+    int L = 1;
+    while (L < 64 && 2 * L <= nchunk) L *= 2;
+    const int per_pass = 256 / L, sub = tid / L, l = tid - sub * L;
+    for (int b0 = 0; b0 < B; b0 += per_pass) {
+        const int b = b0 + sub;
+        double g1 = 0.0, g3 = 0.0;
+        if (b < B) {
+            for (int k = l; k < nchunk; k += L) {
                 const float* q = partial + (((int64_t)b * nchunk + k) * C + c) * 3;
                 g1 += (double)q[0];
                 g3 += (double)q[2];
             }
-            g1 = wave_sum_d(g1);
-            g3 = wave_sum_d(g3);
-            const double d = a * g1 + cq * g3 + hw * bq;
-            if (lane == 0) {
-                dsum[(int64_t)b * C + c] = (float)d;
-                tot += d;
-            }
         }
-    } else {
-        for (int b = lane; b < B; b += 64) {
-            double g1 = 0.0, g3 = 0.0;
-            for (int k = 0; k < nchunk; ++k) {
-                const float* q = partial + (((int64_t)b * nchunk + k) * C + c) * 3;
-                g1 += (double)q[0];
-                g3 += (double)q[2];
-            }
-            const double d = a * g1 + cq * g3 + hw * bq;
-            dsum[(int64_t)b * C + c] = (float)d;
-            tot += d;
+        for (int o = L >> 1; o > 0; o >>= 1) {           // the L lanes of an image sit in one wave
+            g1 += __shfl_xor(g1, o, 64);
+            g3 += __shfl_xor(g3, o, 64);
         }
+        if (b < B && l == 0) dsum[(int64_t)b * C + c] = (float)(a * g1 + cq * g3 + hw * bq);
     }
-    tot = wave_sum_d(tot);
-    if (lane != 0) return;
+    if (tid != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     cA[c] = (float)a;
     cB[c] = (float)bq;
     cC[c] = (float)cq;
-    if (dsum_total) dsum_total[c] = (float)tot;
+    // the sum over the images of a * g1 + cq * g3 + hw * bq, from the totals
+    if (dsum_total) dsum_total[c] = (float)(a * s1 + cq * s3 + count * bq);
 }
 
 // thread per (b, group): coefficients
@@ -592,7 +591,7 @@ int vamd_bn_bwd_finalize_img(const float* partial, int nchunk, int B, int C, int
                              float* dsum_total, int fixed_stats, void* stream) {
     VAMD_REQUIRE(partial && scale && dgamma && dbeta && cA && cB && cC && dsum && nchunk > 0 && B > 0 && C > 0 && HW > 0,
                  "vamd_bn_bwd_finalize_img: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_img_kernel, dim3(C), dim3(64), 0, as_stream(stream), partial, nchunk, B, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_img_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial, nchunk, B, C,
                        (double)HW, scale, dgamma, dbeta, cA, cB, cC, dsum, dsum_total, fixed_stats);
     VAMD_LAUNCH_OK("vamd_bn_bwd_finalize_img");
     return 0;

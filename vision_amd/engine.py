@@ -248,6 +248,51 @@ class _Conv:
             ev.record()
 
 
+# the q / k / v projections of an attention block as one 1x1 convolution over 3C output channels (forward, input
+# gradient and weight gradient: three launches instead of nine, on a layer whose single projections fill a quarter of
+# the chip)
+FUSE_QKV = os.environ.get("VAMD_QKV_FUSE", "1") != "0"
+
+
+class _QKV(_Conv):
+    """q_proj, k_proj and v_proj (reference models/ddpm.py:95-97, applied to the same normalised input at :107-109) as
+    ONE convolution: a filter [3C][C] whose row ranges are the three projections' packed weights (their `wf` become views
+    of it), its transpose [C][3C] for the input gradient (written by the weight re-pack as three column ranges), the
+    concatenated bias, and a weight gradient that lands in the three parameters' own .grad tensors."""
+
+    def __init__(self, eng, q, k, v):
+        Cc = q.cin
+        self.eng, self.name, self.parts = eng, q.name + "|k|v", (q, k, v)
+        self.cin, self.cout, self.k, self.stride, self.up, self.pad = Cc, 3 * Cc, 1, 1, False, 0
+        self.wf = torch.empty((3 * Cc, 1, 1, Cc), dtype=eng.dtype, device=eng.device)
+        self.wd = torch.empty((Cc, 1, 1, 3 * Cc), dtype=eng.dtype, device=eng.device)
+        self.b = torch.empty(3 * Cc, dtype=torch.float32, device=eng.device)
+        self.wd4 = self.wf4 = None
+        self._descs, self._plans = {}, {}
+        for j, c in enumerate(self.parts):
+            c.wf = self.wf[j * Cc:(j + 1) * Cc]              # contiguous row range: the single projection still works
+        self._dw3 = (C.c_void_p * 3)(*[c.gw.data_ptr() for c in self.parts])
+        self._db3 = (C.c_void_p * 3)(*[c.gb.data_ptr() for c in self.parts])
+
+    def repack_items(self):
+        """(conv, fused input-gradient filter's column range, its row length, bias destination) per projection: what the
+        engine's re-pack table needs besides the projections' own entries."""
+        Cc = self.cin
+        return [(c, self.wd.data_ptr() + j * Cc * self.wd.element_size(), 3 * Cc, self.b.data_ptr() + j * Cc * 4)
+                for j, c in enumerate(self.parts)]
+
+    def wgrad(self, dy, x, bias=True, pre=None):
+        B, H, W, _ = x.shape
+        ev = self._timed(2, B, H, W)
+        sp = self.plan(B, H, W)
+        nbytes = sp.wgrad_ws
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+        call("vamd_conv2d_wgrad_oihw_split3", sp.ref, _ptr(dy), _ptr(x), C.byref(self._dw3), C.byref(self._db3) if bias else None,
+             _ptr(ws), nbytes, _stream())
+        if ev is not None:
+            ev.record()
+
+
 class _Linear:
     """A 1x1 conv applied to a [B, C, 1, 1] map (the time-embedding path), kept in fp32."""
 
@@ -515,6 +560,7 @@ class _AttnBlock:
         self.v = _Conv(eng, p + ".v_proj", self.C, self.C, 1)
         self.o = _Conv(eng, p + ".linear", self.C, self.C, 1)
         self.convs = [self.q, self.k, self.v, self.o]
+        self.qkv = _QKV(eng, self.q, self.k, self.v) if FUSE_QKV else None
 
     # Rows of the [S x S] score / probability matrices are padded to Sp = S rounded up to 8
     # elements (16 bytes of bf16) with zeros, so every row is a whole number of 16-byte pieces.
@@ -529,9 +575,10 @@ class _AttnBlock:
         call("vamd_bmm_tn", _ptr(A), _ptr(Bm), _ptr(out), batch, M, N, K, lda, ldb, ldc, 1.0, e.dt, e.algo, _stream())
         return out
 
-    def _transpose_padded(self, t, batch, R, Cc, ld):
+    def _transpose_padded(self, t, batch, R, Cc, ld, ldx=None):
+        """t [batch][R][Cc] (rows ldx apart: t may be a channel range of a wider tensor) -> [batch][Cc][ld], zero padding."""
         out = torch.zeros((batch, Cc, ld), dtype=t.dtype, device=t.device)
-        call("vamd_transpose", _ptr(t), _ptr(out), batch, R, Cc, ld, self.eng.dt, _stream())
+        call("vamd_transpose_ld", _ptr(t), _ptr(out), batch, R, Cc, ldx or Cc, ld, self.eng.dt, _stream())
         return out
 
     def fwd(self, x, temb, training, res2, tape, drop_mask=None, want_stats=False, next_norm=None):
@@ -540,8 +587,14 @@ class _AttnBlock:
         Sp = (S + 7) // 8 * 8
         e, dev = self.eng, x.device
         hn, coef = self.norm.fwd(x, training)
-        q, k, v = self.q.fwd(hn), self.k.fwd(hn), self.v.fwd(hn)
-        if tape is None and FUSE_ATTENTION and lib.vamd_attention_fwd_supported(S, Cc, e.dt):
+        fuse_core = tape is None and FUSE_ATTENTION and lib.vamd_attention_fwd_supported(S, Cc, e.dt)
+        # (the fused form needs the MFMA weight-gradient kernel, which writes the three parameters' gradients separately)
+        if self.qkv is not None and not fuse_core and self.qkv.plan(B, H, W).mfma[2]:
+            qkv = self.qkv.fwd(hn)                            # [B][H][W][3C]: q, k, v are its channel ranges (rows 3C apart)
+            q, k, v, ld = qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 3 * Cc
+        else:
+            q, k, v, ld = self.q.fwd(hn), self.k.fwd(hn), self.v.fwd(hn), Cc
+        if fuse_core:
             # no backward to follow: scores, softmax and the product with the values in one kernel, nothing S x S in HBM
             vT = self._transpose_padded(v, B, S, Cc, Sp)
             o = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)
@@ -552,10 +605,10 @@ class _AttnBlock:
                 return got[1]
             return self.o.fwd(o, res=x, res2=res2)
         scores = torch.empty((B, S, Sp), dtype=torch.float32, device=dev)     # [B][query][key]
-        self._bmm_nt(q, k, scores, B, S, S, Cc, Cc, Cc, Sp, Cc ** -0.5)
+        self._bmm_nt(q, k, scores, B, S, S, Cc, ld, ld, Sp, Cc ** -0.5)
         P = torch.zeros((B, S, Sp), dtype=e.dtype, device=dev)
         call("vamd_softmax_rows", _ptr(scores), _ptr(P), B * S, S, Sp, e.dt, _stream())
-        vT = self._transpose_padded(v, B, S, Cc, Sp)                          # [B][C][Sp]
+        vT = self._transpose_padded(v, B, S, Cc, Sp, ldx=ld)                  # [B][C][Sp]
         o = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)             # o[s][c] = sum_t P[s][t] v[t][c]
         self._bmm_nt(P, vT, o, B, S, Cc, S, Sp, Sp, Cc, 1.0)
         got = self.o.fwd_act(o, next_norm, res=x, res2=res2, want_raw=True) if next_norm is not None else None
@@ -575,21 +628,30 @@ class _AttnBlock:
         Sp = P.shape[2]
         self.o.wgrad(dy, o)
         do = self.o.dgrad(dy, o.shape)
+        ld = q.stride(2)                                                      # 3C when q, k, v are ranges of one tensor
+        fused = self.qkv is not None and ld == 3 * Cc
+        if fused:
+            dqkv = torch.empty((B, H, W, 3 * Cc), dtype=e.dtype, device=dev)
+            dq, dk, dv, ldg = dqkv[..., :Cc], dqkv[..., Cc:2 * Cc], dqkv[..., 2 * Cc:], 3 * Cc
+        else:
+            dq, dk, dv = (torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev) for _ in range(3))
+            ldg = Cc
         dP = torch.empty((B, S, Sp), dtype=torch.float32, device=dev)         # dP[s][t] = sum_c do[s][c] v[t][c]
-        self._bmm_nt(do, v, dP, B, S, S, Cc, Cc, Cc, Sp, 1.0)
-        dv = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)            # dv[t][c] = sum_s P[s][t] do[s][c]
-        self._bmm_tn(P, do, dv, B, S, Cc, S, Sp, Cc, Cc)
+        self._bmm_nt(do, v, dP, B, S, S, Cc, Cc, ld, Sp, 1.0)
+        self._bmm_tn(P, do, dv, B, S, Cc, S, Sp, Cc, ldg)                     # dv[t][c] = sum_s P[s][t] do[s][c]
         dS = torch.zeros((B, S, Sp), dtype=e.dtype, device=dev)
         call("vamd_softmax_rows_bwd", _ptr(P), _ptr(dP), _ptr(dS), B * S, S, Sp, Cc ** -0.5, e.dt, _stream())
-        kT = self._transpose_padded(k, B, S, Cc, Sp)
-        dq = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)            # dq[s][c] = sum_t dS[s][t] k[t][c]
-        self._bmm_nt(dS, kT, dq, B, S, Cc, S, Sp, Sp, Cc, 1.0)
-        dk = torch.empty((B, H, W, Cc), dtype=e.dtype, device=dev)            # dk[t][c] = sum_s dS[s][t] q[s][c]
-        self._bmm_tn(dS, q, dk, B, S, Cc, S, Sp, Cc, Cc)
-        dhn = None
-        for conv, g in ((self.q, dq), (self.k, dk), (self.v, dv)):
-            conv.wgrad(g, hn)
-            dhn = conv.dgrad(g, hn.shape, add=dhn)
+        kT = self._transpose_padded(k, B, S, Cc, Sp, ldx=ld)
+        self._bmm_nt(dS, kT, dq, B, S, Cc, S, Sp, Sp, ldg, 1.0)               # dq[s][c] = sum_t dS[s][t] k[t][c]
+        self._bmm_tn(dS, q, dk, B, S, Cc, S, Sp, ld, ldg)                     # dk[t][c] = sum_s dS[s][t] q[s][c]
+        if fused:
+            self.qkv.wgrad(dqkv, hn)
+            dhn = self.qkv.dgrad(dqkv, hn.shape)
+        else:
+            dhn = None
+            for conv, g in ((self.q, dq), (self.k, dk), (self.v, dv)):
+                conv.wgrad(g, hn)
+                dhn = conv.dgrad(g, hn.shape, add=dhn)
         return self.norm.bwd(dhn, x, coef, None, add=dy, add2=extra, need_dx=need_dx)
 
 
@@ -857,15 +919,22 @@ class Engine:
         vers = [p._version for p in self._params]
         if self.dirty or vers != self._versions:
             if self._repack_table is None:                    # device table of every conv, built once
-                convs = list(self.all_convs())
-                items = (RepackItem * len(convs))()
+                # (conv, input-gradient filter, its row length or 0, bias destination or 0); the fused q / k / v projections
+                # of the attention blocks add one entry per projection for their side-by-side input-gradient filter
+                entries = [(c, c.wd.data_ptr(), 0, 0) for c in self.all_convs()]
+                for layer in self.layers:
+                    if getattr(layer, "qkv", None) is not None:
+                        entries += layer.qkv.repack_items()
+                items = (RepackItem * len(entries))()
                 blocks = 0
-                for it, c in zip(items, convs):
-                    it.w, it.w_fwd, it.w_dgrad = c.w.data_ptr(), c.wf.data_ptr(), c.wd.data_ptr()
+                for it, (c, wd, ld, bias_out) in zip(items, entries):
+                    it.w, it.w_fwd, it.w_dgrad, it.ld_dgrad = c.w.data_ptr(), c.wf.data_ptr(), wd, ld
                     it.first_block, it.Cout, it.Cin, it.ksize = blocks, c.cout, c.cin, c.k
+                    if bias_out:
+                        it.bias, it.bias_out = c.b.data_ptr(), bias_out
                     blocks += ((c.cout + 31) // 32) * ((c.cin + 31) // 32)
                 raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
-                self._repack_table = (raw, len(convs), blocks)
+                self._repack_table = (raw, len(entries), blocks)
             raw, n, blocks = self._repack_table
             call("vamd_repack_weights", _ptr(raw), n, blocks, self.dt, _stream())
             for c in self.all_convs():
