@@ -54,6 +54,8 @@ TOL = {
 # three AdamW steps, fp32 compute, update of every parameter tensor against the reference's: over all elements, over the
 # elements whose update has the reference's direction, and the share of elements that moved the other way
 ADAM_REL_ALL, ADAM_REL_KEPT, ADAM_FLIPPED = 0.4, 0.4, 0.2
+# ... and of all parameters as one vector: measured 0.005 - 0.085 on the four fixtures, bound = twice the largest
+ADAM_REL_GLOBAL = 0.17
 
 
 def rel(a, b):
@@ -225,6 +227,7 @@ def test_three_adamw_steps_then_eval_and_sample(golden, mode):
     sd = m.state_dict()
     p0 = sub(g, "state0")
     lr = cfg["learning_rate"]
+    all_du, all_dv = [], []
     for k, v in sub(g, "state3").items():
         if v.dtype == torch.int64:
             assert int(sd[k]) == int(v), k
@@ -245,6 +248,17 @@ def test_three_adamw_steps_then_eval_and_sample(golden, mode):
                         f.write(f"{mode} {k} numel {v.numel()} flipped {int(flipped.sum())} rel_all {r_all:.4f} rel_kept {r_kept:.4f}\n")
                 assert r_all < ADAM_REL_ALL and r_kept < ADAM_REL_KEPT and flipped.float().mean().item() <= ADAM_FLIPPED, \
                     (k, r_all, r_kept, int(flipped.sum()), v.numel())
+                all_du.append(du.flatten().double())
+                all_dv.append(dv.flatten().double())
+    if all_du:
+        # the three-step update of the whole model (every tensor above in one vector): the single BatchNorm tensors that
+        # reach 0.16 - 0.31 hold 32 - 64 elements each; over all parameters the update agrees to ADAM_REL_GLOBAL
+        du, dv = torch.cat(all_du), torch.cat(all_dv)
+        r_glob = ((du - dv).norm() / dv.norm()).item()
+        if os.environ.get("VAMD_TEST_REPORT"):
+            with open(os.environ["VAMD_TEST_REPORT"], "a") as f:
+                f.write(f"{mode} GLOBAL numel {dv.numel()} rel_all {r_glob:.5f}\n")
+        assert r_glob < ADAM_REL_GLOBAL, r_glob
 
     # validation loss + sampler from the REFERENCE's trained state (isolates them from step drift)
     m2 = make_model(cfg, sub(g, "state3"), mode).eval()
