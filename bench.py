@@ -1,6 +1,9 @@
 """Benchmark of the DDPM UNet training step (and sampler) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--preset butterfly|flowers|ffhq|vqvaeunet|ldm] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--preset butterfly|flowers|ffhq|vqvaeunet|ldm] [--batch B] [--graph]
+
+`--graph`: the timed steps are replays of ONE captured training step (vision_amd.graphed.GraphedTrainStep: the host issues a
+step in ~0.15 ms instead of 4-12 ms; same kernels, same order).
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process, before it touches a GPU, starts
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a child process
@@ -17,7 +20,10 @@ batch 64 per GPU, 224x224, bf16 compute.  N > 1 is weak scaling (64 images per G
 Rank 0 prints ONE JSON line: metric value = training images/s over all GPUs, plus
   roofline     - the MFMA implicit-GEMM kernel (forward + input-gradient launches): algorithmic
                  FLOPs / device time, from HIP events the library records on the launch stream
-                 right before and after every launch of that kernel in the timed steps;
+                 right before and after every launch of that kernel, over up to 20 further steps
+                 issued right after the timed ones (the ~220 event packets a step needs cost it
+                 about 0.65 ms, so the K timed steps run without them; `ms_per_step_with_launch_events`
+                 is the instrumented steps' time);
   cpu_baseline - the oracle's CPU restatement timed on a bounded sample of configs[0]
                  (flowers model, batch 8), N = 1 only.
 """
@@ -49,6 +55,9 @@ def parse():
     ap.add_argument("--preset", default="butterfly")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the preset's data_config.batch_size)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the training step into a HIP graph (vision_amd.graphed) and time its replays; the per-launch "
+                         "roofline figures are then taken over 10 eager steps before the capture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--sample-steps", type=int, default=None,
@@ -286,8 +295,12 @@ def main():
     batches = [(torch.rand((B, 3, P, P), generator=gen).to(dev), torch.zeros(B, dtype=torch.int64, device=dev))
                for _ in range(nbatch)]
 
+    stepper = None
+
     def step(i):
         dp.broadcast_buffers()
+        if stepper is not None:
+            return stepper(batches[i % nbatch], i)
         loss = model.training_step(batches[i % nbatch], i)
         loss.backward()
         opt.step()
@@ -308,19 +321,25 @@ def main():
 
     fence()
     trace("warmup done")
-    # per-launch HIP events inside the library, on the launch stream, around every MFMA conv kernel;
-    # VAMD_BENCH_LAYERS=1 adds per-call events in the engine for a per-layer table
-    layers = bool(os.environ.get("VAMD_BENCH_LAYERS"))
-    prof = []                 # (kind, flops, start_event, end_event, shape) per MFMA conv call
-    lib.vamd_launch_timing(1)
+    import ctypes
+    if args.graph:
+        from vision_amd.graphed import GraphedTrainStep
+        stepper = GraphedTrainStep(model, opt)
+        for i in range(3):                      # two eager steps, then the capture and its first replay
+            step(args.warmup + i)
+        fence()
+        trace("graph captured")
     dp.reducer.timing = []        # (event after the last backward kernel, event after the last bucket has landed) per step
+    # ---- the timed steps.  The library's per-launch events are OFF here: two event packets around each of a step's ~110
+    # MFMA launches cost the step about 0.65 ms (3.5 % of the butterfly step, 9 % of the flowers step, measured against
+    # the same steps without them), so the roofline figures are taken over the steps that follow, not over these.
     # Host time to issue a step: taken over the first steps after the fence, while the device queue still has room.
     # (The host may run ahead of the device by a bounded number of launches, about four steps' worth here; past that
     # every launch call blocks until the device has retired one, and the host's pace is the device's.)
+    lib.vamd_launch_timing(0)
     n_free = min(4, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.profile = prof if layers else None
         loss = step(args.warmup + i)
         if i + 1 == n_free:
             host_free = (time.perf_counter() - t0) / n_free
@@ -328,8 +347,6 @@ def main():
     fence()
     trace("timed steps done")
     elapsed = time.perf_counter() - t0
-    eng.profile = None
-    lib.vamd_launch_timing(0)
     if grouped:
         tmax = torch.tensor([elapsed], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -339,8 +356,22 @@ def main():
     ips = world * B * args.steps / elapsed
     final_loss = float(loss.detach())
 
-    # roofline of the dominant kernel: persistent MFMA implicit-GEMM (forward + input gradient)
-    import ctypes
+    # ---- the same steps again (launch by launch, also after --graph) with HIP events recorded inside the library on the
+    # launch stream, directly around every MFMA convolution launch: the roofline of the dominant kernel.
+    # VAMD_BENCH_LAYERS=1 adds per-call events in the engine for a per-layer table.
+    layers = bool(os.environ.get("VAMD_BENCH_LAYERS"))
+    prof = []                 # (kind, flops, start_event, end_event, shape) per MFMA conv call
+    n_inst = min(args.steps, 20)
+    stepper = None
+    lib.vamd_launch_timing(1)
+    t1 = time.perf_counter()
+    for i in range(n_inst):
+        eng.profile = prof if layers else None
+        step(args.warmup + args.steps + i)
+    fence()
+    inst_ms = 1e3 * (time.perf_counter() - t1) / n_inst
+    eng.profile = None
+    lib.vamd_launch_timing(0)
 
     def timed(kind):
         ms, fl, ex = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
@@ -366,6 +397,9 @@ def main():
                 # upsampling convolution execute 16/36 of the operator's count) beside it
                 "executed_tflops": round(fx / (t * 1e-3) / 1e12, 1),
                 "executed_frac": round(fx / (t * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
+    if roof is not None:
+        roof["measured_over"] = (f"{n_inst} steps issued right after the timed ones with the library's per-launch HIP events on "
+                                 f"({inst_ms:.3f} ms per step with the events)")
     f, t, n, fx = timed(1)
     if n:
         conv_ms += t
@@ -379,7 +413,8 @@ def main():
         for shape, (f, t, n) in sorted(per_shape.items(), key=lambda kv: -kv[1][1]):
             print("layer %-52s calls %3d  %7.3f ms/call  %7.1f TFLOP/s  %5.1f%% of MFMA conv time" % (
                 str(shape), n, t / n, f / (t * 1e-3) / 1e12, 100 * t / sum(v[1] for v in per_shape.values())), file=sys.stderr)
-    extra["mfma_conv_ms_per_step"] = round(conv_ms / args.steps, 3)
+    extra["mfma_conv_ms_per_step"] = round(conv_ms / n_inst, 3)
+    extra["ms_per_step_with_launch_events"] = round(inst_ms, 3)
     # host time to issue a step's launches vs the step's wall time: the step is device-bound while the first
     # stays below the second
     extra["host_issue_ms_per_step"] = round(1e3 * host_free, 3)
@@ -437,6 +472,7 @@ def main():
             "train_tflops_per_s": round(ips * tf / 1e12, 1),
             "train_frac_of_bf16_mfma_peak": round(ips * tf / 1e12 / (BF16_MFMA_PEAK_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
+            "graph_replay": bool(args.graph),
             "roofline": roof, "sampling": sampling, **extra,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -432,6 +432,12 @@ int vamd_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
 int vamd_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                  int step, float grad_scale, void* stream);
+/* The same update with BOTH scalars that change from step to step read from device memory: lr_dev[0] and the 1-based
+ * step count step_dev[0] (the bias corrections 1 - beta^step are formed in the kernel).  For a training step captured
+ * into a HIP graph once and replayed: the launch's arguments never change, the caller increments step_dev on the device
+ * (inside the graph) and rewrites lr_dev when a scheduler moves the rate.  l2_decay != 0 selects vamd_adam_l2's rule. */
+int vamd_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, const int64_t* step_dev,
+                  float beta1, float beta2, float eps, float weight_decay, float grad_scale, int l2_decay, void* stream);
 
 /* out[i] = a[i] (+ b[i] when b != NULL), i < n; every operand has its own dtype, the sum is taken in fp32.  The dtype
  * changes and two-term merges around the first stage's codebook lookup: the latents and their gradient are fp32 between

@@ -825,6 +825,26 @@ def test_adamw_matches_torch():
     assert relerr(p, ref.detach()) < 1e-6
 
 
+@pytest.mark.parametrize("l2", [0, 1])
+def test_adam_with_step_count_and_rate_on_the_device(l2):
+    """vamd_adam_dev (learning rate and step count read from device memory, bias corrections formed in the kernel) against
+    vamd_adamw / vamd_adam_l2 with the host's values, at steps 1, 2, 10 and 1000: the same update to 2e-5 of its size (fp32 powf against the host's double)."""
+    gen = torch.Generator().manual_seed(9)
+    n = 4099
+    for step in (1, 2, 10, 1000):
+        p0 = torch.randn(n, generator=gen).to(DEV)
+        g = torch.randn(n, generator=gen).to(DEV)
+        m0 = (torch.randn(n, generator=gen) * 0.1).to(DEV)
+        v0 = (torch.rand(n, generator=gen) * 0.01).to(DEV)
+        a, b = (p0.clone(), m0.clone(), v0.clone()), (p0.clone(), m0.clone(), v0.clone())
+        call("vamd_adam_l2" if l2 else "vamd_adamw", P(a[0]), P(g), P(a[1]), P(a[2]), n, 3e-3, None, 0.9, 0.999, 1e-8, 1e-2, step, 0.5, S())
+        lr_dev = torch.full((1,), 3e-3, device=DEV)
+        step_dev = torch.full((1,), step, dtype=torch.int64, device=DEV)
+        call("vamd_adam_dev", P(b[0]), P(g), P(b[1]), P(b[2]), n, P(lr_dev), P(step_dev), 0.9, 0.999, 1e-8, 1e-2, 0.5, l2, S())
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert ((a[0] - b[0]).norm() / (a[0] - p0).norm()).item() < 2e-5, step
+
+
 @pytest.mark.parametrize("dts", ["f32", "bf16"])
 def test_repack_weights_batched_matches_single(dts):
     """One launch over a table of convolutions == vamd_repack_weight per convolution."""

@@ -300,3 +300,22 @@ def test_bench_presets_print_one_json_line(preset):
     assert line["exchange"]["ranks"] == 1 and not line["exchange"]["live"]
     assert ("sampling" in line) and (line["sampling"] is None) == (preset == "vqvaeunet")
     assert "layer (" in r.stderr
+
+
+def test_bench_with_a_captured_step():
+    """bench.py --graph: the timed steps are replays of one captured training step; the line says so, the host issues a
+    step in a fraction of a millisecond, and the roofline object (from the instrumented steps after the timed ones) is still there."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--preset", "flowers", "--batch", "2", "--steps", "4",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-sampling", "--graph"], cwd=root, capture_output=True,
+                       text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["graph_replay"] is True and line["value"] > 0 and line["steps"] == 4
+    assert 0 < line["host_issue_ms_per_step"] < 1.0, line["host_issue_ms_per_step"]
+    assert line["roofline"]["launches"] > 0 and "per-launch HIP events" in line["roofline"]["measured_over"]
+    assert 0 < line["final_loss"] < 5

@@ -228,3 +228,46 @@ def test_configure_optimizers_quirks(golden):
     x = g["x_t"].to(DEV).requires_grad_(True)
     with pytest.raises(RuntimeError, match="parameter gradients only"):
         m(x, (g["sched_n"] ** 2).to(DEV))
+
+
+def test_graph_replayed_steps_equal_eager_steps():
+    """Training steps replayed from a HIP graph (vision_amd.graphed.GraphedTrainStep: two eager steps, one capture, replays)
+    against the same steps issued launch by launch: identical losses, parameters, BatchNorm buffers and step counts after
+    six steps on changing batches, with a learning rate that changes on the way (the optimiser reads it from the device)."""
+    import vision_amd
+    from vision_amd.graphed import GraphedTrainStep
+    cfg = dict(name="ddpm", input_channels=3, learning_rate=1e-3, manual_seed=42, h_dims=[3, 32, 64, 64], down_index=[0, 1, 1, 1],
+               attn_res=[8], with_conv=True, dropout=0.1, latent_dim=64, sampling_period=1, weight_decay=1e-3,
+               diffusion_steps=4, scheduler_gamma=0.9, patch_size=32, grid=2)
+    gen = torch.Generator().manual_seed(3)
+    batches = [(torch.rand((4, 3, 32, 32), generator=gen).to(DEV), torch.zeros(4, dtype=torch.int64, device=DEV)) for _ in range(6)]
+    out = []
+    for graphed, on_device in ((False, True), (True, True)):
+        torch.manual_seed(7)
+        model = vision_amd.get_model("ddpm", cfg, compute_dtype="bf16").to(DEV).train()
+        (opt,), (sched,) = model.configure_optimizers()
+        if on_device and not graphed:
+            opt.make_capturable()                   # the same optimiser launch as the graph's: step count and rate on the device
+        stepper = GraphedTrainStep(model, opt) if graphed else None
+        torch.manual_seed(11)                       # noise, diffusion times and dropout masks of the six steps
+        torch.cuda.manual_seed(11)
+        losses = []
+        for i, b in enumerate(batches):
+            if graphed:
+                losses.append(stepper(b, i))
+            else:
+                loss = model.training_step(b, i)
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach().clone())
+            if i == 3:
+                sched.step()                        # the rate changes between two replays
+        eng = model._ensure_engine()
+        torch.cuda.synchronize()
+        out.append((torch.stack(losses).cpu(), eng.flat_p.clone(), eng.flat_b.clone(), eng.flat_nbt.clone(), opt.state_steps(),
+                    len(model.train_losses), torch.stack([l.detach() for l in model.train_losses]).cpu()))
+    (l0, p0, b0, n0, s0, k0, t0), (l1, p1, b1, n1, s1, k1, t1) = out
+    assert s0 == s1 == 6 and k0 == k1 == 6
+    assert torch.equal(l0, l1) and torch.equal(t0, t1) and torch.equal(l1, t1)
+    assert torch.equal(b0, b1) and torch.equal(n0, n1)
+    assert torch.equal(p0, p1)

@@ -147,6 +147,7 @@ SIGNATURES = {
     "vamd_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vamd_adamw": (_i, [_p, _p, _p, _p, _l, _f, _p, _f, _f, _f, _f, _i, _f, _p]),
     "vamd_adam_l2": (_i, [_p, _p, _p, _p, _l, _f, _p, _f, _f, _f, _f, _i, _f, _p]),
+    "vamd_adam_dev": (_i, [_p, _p, _p, _p, _l, _p, _p, _f, _f, _f, _f, _f, _i, _p]),
     "vamd_resize_ksize": (_i, [_i, _i]),
     "vamd_resize_coeffs": (_i, [_i, _i, _p, _p, _i]),
     "vamd_image_resize_u8": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p, _i, _i, _p, _p, _p]),

@@ -579,8 +579,13 @@ template <bool L2>
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                              float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                              const float* __restrict__ lr_dev, float beta1, float beta2, float eps,
-                             float wd, float bc1, float rsqrt_bc2, float gscale) {
+                             float wd, float bc1, float rsqrt_bc2, float gscale, const int64_t* __restrict__ step_dev) {
     if (lr_dev) lr = lr_dev[0];
+    if (step_dev) {                                      // the step count lives on the device (a captured launch is replayed)
+        const float st = (float)step_dev[0];
+        bc1 = 1.f - powf(beta1, st);
+        rsqrt_bc2 = rsqrtf(1.f - powf(beta2, st));
+    }
     const float step_size = lr / bc1;
     const float decay = L2 ? 1.f : 1.f - lr * wd;
     const float l2 = L2 ? wd : 0.f;
@@ -1192,19 +1197,19 @@ int vamd_linear_bwd_multi(const float* x, const vamd_linear_bwd_item* items, int
 
 static int adam_launch(const char* what, bool l2, float* p, const float* g, float* m, float* v, int64_t n, float lr,
                        const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int step,
-                       float grad_scale, void* stream) {
-    VAMD_REQUIRE(p && g && m && v && n > 0 && step >= 1, "%s: bad argument", what);
+                       float grad_scale, void* stream, const int64_t* step_dev = nullptr) {
+    VAMD_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev), "%s: bad argument", what);
     VAMD_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) &&
                      ((uintptr_t)v % 16 == 0), "%s: arenas must be 16-byte aligned", what);
-    const double bc1 = 1.0 - pow((double)beta1, step);
-    const double bc2 = 1.0 - pow((double)beta2, step);
+    const double bc1 = 1.0 - pow((double)beta1, step >= 1 ? step : 1);
+    const double bc2 = 1.0 - pow((double)beta2, step >= 1 ? step : 1);
     const dim3 grid(grid_for(n / 4 + 1, 256, 2048));
     if (l2)
         hipLaunchKernelGGL(adamw_kernel<true>, grid, dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, lr_dev, beta1, beta2,
-                           eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+                           eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, step_dev);
     else
         hipLaunchKernelGGL(adamw_kernel<false>, grid, dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, lr_dev, beta1, beta2,
-                           eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+                           eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, step_dev);
     VAMD_LAUNCH_OK(what);
     return 0;
 }
@@ -1219,6 +1224,13 @@ int vamd_adam_l2(float* p, const float* g, float* m, float* v, int64_t n, float 
                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                  int step, float grad_scale, void* stream) {
     return adam_launch("vamd_adam_l2", true, p, g, m, v, n, lr, lr_dev, beta1, beta2, eps, weight_decay, step, grad_scale, stream);
+}
+
+int vamd_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev, const int64_t* step_dev,
+                  float beta1, float beta2, float eps, float weight_decay, float grad_scale, int l2_decay, void* stream) {
+    VAMD_REQUIRE(lr_dev && step_dev, "vamd_adam_dev: null device scalar");
+    return adam_launch("vamd_adam_dev", l2_decay != 0, p, g, m, v, n, 0.f, lr_dev, beta1, beta2, eps, weight_decay, 0, grad_scale,
+                       stream, step_dev);
 }
 
 int vamd_repack_weight(const float* w, void* wf, void* wd, int Cout, int Cin, int ksize, int dtype,

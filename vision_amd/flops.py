@@ -58,3 +58,22 @@ def latent_train_flops_per_image(config):
     """The latent-space UNet of reference models/ldm.py on one latent map."""
     total, skip = forward_flops_per_image(config, make_ldm_plan(config), channel_attention=True)
     return 3.0 * total - skip
+
+
+def norm_elems_per_image(config, plan=None):
+    """(BatchNorm'd, GroupNorm'd) activation elements of one image's forward: every ResNetBlock normalises its input
+    (cin channels) and the output of its first convolution (cout channels) at the block's resolution; an attention block
+    normalises its input once.  The byte counts of the normalisation passes are multiples of these."""
+    plan = plan or make_plan(config)
+    res = plan.patch_size
+    bn, gn = 0.0, 0.0
+    for spec in plan.layers:
+        if spec.kind == "res":
+            bn += (spec.cin + spec.cout) * res * res
+        elif spec.kind == "attn":
+            gn += spec.cout * res * res
+        elif spec.kind == "down":
+            res = (res - 1) // 2 + 1 if plan.with_conv else res // 2
+        else:
+            res = res * 2
+    return bn, gn

@@ -185,7 +185,7 @@ class Trainer:
 
     def __init__(self, logger: Optional[DirLogger] = None, callbacks=(), max_epochs=1, precision="16-mixed",
                  accelerator="gpu", devices=1, max_steps=-1, limit_val_batches=None, log_every_n_steps=1,
-                 enable_checkpointing=False, enable_progress_bar=False, num_nodes=1, distributed=True, **_):
+                 enable_checkpointing=False, enable_progress_bar=False, num_nodes=1, distributed=True, graph_step=False, **_):
         """distributed=False: a single-process trainer even when a process group is up (no broadcasts, no
         scalar all-reduce) - what the reference's rank-0 `Trainer(devices=1).test(...)` after fit is
         (run.py:93-96); with the group's collectives it would wait for ranks that never call them."""
@@ -195,6 +195,7 @@ class Trainer:
         self.current_epoch, self.global_step = 0, 0
         self.callback_metrics = {}
         self.distributed = bool(distributed)
+        self.graph_step = bool(graph_step)
         self.global_rank, self.world_size = world_info() if self.distributed else (0, 1)
         self.lightning_module = None
         self._epoch_sums = {}
@@ -257,6 +258,12 @@ class Trainer:
         for cb in self.callbacks:
             if hasattr(cb, "on_train_start") and self.is_global_zero:
                 cb.on_train_start(self, model)
+        # VAMD_GRAPH=1 (or Trainer(graph_step=True)): the training step is captured into a HIP graph after two eager steps
+        # and replayed (vision_amd.graphed: one host call per step; ragged last batches still run eagerly)
+        stepper, graph_shape = None, None
+        if getattr(self, "graph_step", False) or os.environ.get("VAMD_GRAPH") == "1":
+            from .graphed import GraphedTrainStep
+            stepper = GraphedTrainStep(model, opt)
         done = False
         for epoch in range(self.max_epochs):
             self.current_epoch = epoch
@@ -266,9 +273,14 @@ class Trainer:
             for i, batch in enumerate(datamodule.train_dataloader(self.global_rank, self.world_size)):
                 if self.dp is not None:
                     self.dp.broadcast_buffers()
-                loss = model.training_step(batch, i)
-                loss.backward()
-                opt.step()
+                shape = tuple(batch[0].shape)
+                if stepper is not None and (graph_shape is None or shape == graph_shape):
+                    graph_shape = shape
+                    loss = stepper(batch, i)
+                else:
+                    loss = model.training_step(batch, i)
+                    loss.backward()
+                    opt.step()
                 self.global_step += 1
                 if 0 < self.max_steps <= self.global_step:
                     done = True
