@@ -158,12 +158,12 @@ def cpu_baseline_latent(kind, seconds_budget=16.0):
             "steps": steps, "batch": B, "sample": what}
 
 
-TRAFFIC_CSV = "r2_pmc_tcc_traffic.csv"
+TRAFFIC_CSV = "r3_pmc_tcc_traffic.csv"
 
 
 def measured_traffic(*kernel_substrs):
     """HBM bytes per launch of the kernels whose name contains one of `kernel_substrs`, from the committed
-    counter pass profiles/r2_pmc_tcc_traffic.csv ((2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, same
+    counter pass profiles/r3_pmc_tcc_traffic.csv ((2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, same
     workload).  The file's first line carries the hash of the kernel sources it was collected with: None when
     the file is missing or the kernels in the tree have changed since (counters cannot be collected inside
     a timed run, so a stale figure is dropped rather than reported)."""

@@ -212,6 +212,8 @@ typedef struct vamd_repack_item {
                             * output channels are a column range of a wider filter (q / k / v projections side by side) */
     const float* bias;     /* with bias_out != NULL: bias_out[0 .. Cout) = bias[0 .. Cout) in the same launch */
     float* bias_out;
+    void* w_up4_dgrad;     /* 3x3 filters of an upsampling convolution: what vamd_repack_weight_up4 writes, or NULL */
+    void* w_up4_fwd;       /* ... and what vamd_repack_weight_up4_fwd writes, or NULL */
 } vamd_repack_item;
 int vamd_repack_weights(const vamd_repack_item* items, int n, long long total_blocks, int dtype, void* stream);
 /* fp32 [Cout][k][k][Cin] -> fp32 [Cout][Cin][k][k] (gradient back to torch layout). */

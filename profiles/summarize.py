@@ -141,7 +141,7 @@ def family_table(preset, stats_csv, bench_line, steps_traced):
 def write_family_tables(root):
     """root/trace_<preset>/ (profiles/trace_presets.sh) -> profiles/r3_<preset>_kernel_stats.csv and one table file."""
     tables = []
-    for preset, steps in (("butterfly", 13), ("flowers", 13), ("ffhq", 7)):
+    for preset in ("butterfly", "flowers", "ffhq"):
         d = os.path.join(root, "trace_" + preset)
         hits = sorted(glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
         if not hits:
@@ -151,6 +151,10 @@ def write_family_tables(root):
         line = [ln for ln in open(os.path.join(d, "bench.log")) if ln.startswith("{")][-1]
         with open(os.path.join(HERE, f"{ROUND}_{preset}_bench_line_profiled.json"), "w") as f:
             f.write(line)
+        import json
+        d = json.loads(line)
+        # the profiled process runs the warm-up steps, the timed steps and the instrumented steps that follow them
+        steps = d["warmup"] + d["steps"] + min(d["steps"], 20) + (3 if d.get("graph_replay") else 0)
         tables.append(family_table(preset, dst, line, steps))
     with open(os.path.join(HERE, f"{ROUND}_kernel_families.md"), "w") as f:
         f.write("\n".join(tables))

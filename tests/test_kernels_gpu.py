@@ -864,12 +864,24 @@ def test_repack_weights_batched_matches_single(dts):
         it.first_block, it.Cout, it.Cin, it.ksize = blocks, O, I, k
         blocks += ((O + 31) // 32) * ((I + 31) // 32)
         keep.append((w, wf, wd, wf1, wd1))
+    # the 3 x 3 entries also carry the combined filters of an upsampling convolution
+    up = []
+    for it, (O, I, k), (w, *_rest) in zip(items, shapes, keep):
+        if k != 3:
+            continue
+        g4, f4 = torch.full((I, 4, 4, O), 7.0, dtype=tdt, device=DEV), torch.full((4, O, 2, 2, I), 7.0, dtype=tdt, device=DEV)
+        g41, f41 = torch.empty_like(g4), torch.empty_like(f4)
+        call("vamd_repack_weight_up4", P(w), P(g41), O, I, dt, S())
+        call("vamd_repack_weight_up4_fwd", P(w), P(f41), O, I, dt, S())
+        it.w_up4_dgrad, it.w_up4_fwd = g4.data_ptr(), f4.data_ptr()
+        up.append((g4, f4, g41, f41))
     table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(DEV)
     call("vamd_repack_weights", P(table), len(shapes), blocks, dt, S())
     torch.cuda.synchronize()
     for w, wf, wd, wf1, wd1 in keep:
         assert torch.equal(wf, wf1) and torch.equal(wd, wd1)
         assert torch.equal(wf.float(), w.permute(0, 2, 3, 1).to(tdt).float())
+    assert up and all(torch.equal(g4, g41) and torch.equal(f4, f41) for g4, f4, g41, f41 in up)
 
 
 @pytest.mark.parametrize("dts", ["f32", "bf16"])

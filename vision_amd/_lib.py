@@ -50,7 +50,7 @@ CONV_SCRATCH_BYTES = 4096 + 256 * 256 * 256 * 4      # VAMD_CONV_SCRATCH_BYTES
 class RepackItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p), ("first_block", C.c_longlong),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("ld_dgrad", C.c_int32),
-                ("bias", C.c_void_p), ("bias_out", C.c_void_p)]
+                ("bias", C.c_void_p), ("bias_out", C.c_void_p), ("w_up4_dgrad", C.c_void_p), ("w_up4_fwd", C.c_void_p)]
 
 
 class LinearItem(C.Structure):

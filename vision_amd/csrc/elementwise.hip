@@ -689,6 +689,39 @@ repack_weights_kernel(const vamd_repack_item* __restrict__ items, int n) {
             if (o < O && i < I) wf[((int64_t)o * kk + tap) * I + i] = from_f<T>(tile[ol][il * kk + tap]);
         }
     }
+    // The two combined filters of an upsampling convolution (nearest 2x -> 3x3), from the same tile: the 4x4 stride-2
+    // filter of its input gradient, w_up4_dgrad [I][4][4][O] (along each axis tap t collects the conv taps {2}, {1,2},
+    // {0,1}, {0}), and the four 2x2 class filters of its forward, w_up4_fwd [ph*2+pw][O][a][b][I] (ph = 0: a = 0 -> {0},
+    // a = 1 -> {1,2}; ph = 1: a = 0 -> {0,1}, a = 1 -> {2}); sums formed in fp32 and rounded once.
+    if (it.w_up4_dgrad && kk == 9) {
+        T* __restrict__ g4 = (T*)it.w_up4_dgrad;
+        for (int idx = threadIdx.x; idx < TI * 16 * TO; idx += 256) {  // [i][t][u][o], o fastest
+            const int ol = idx % TO, u = (idx / TO) & 3, t = (idx / (TO * 4)) & 3, il = idx / (TO * 16);
+            const int o = o0 + ol, i = i0 + il;
+            if (o >= O || i >= I) continue;
+            const int r_lo = t == 0 ? 2 : (t == 1 ? 1 : 0), r_hi = t <= 1 ? 2 : (t == 2 ? 1 : 0);
+            const int s_lo = u == 0 ? 2 : (u == 1 ? 1 : 0), s_hi = u <= 1 ? 2 : (u == 2 ? 1 : 0);
+            float sum = 0.f;
+            for (int r = r_lo; r <= r_hi; ++r)
+                for (int q = s_lo; q <= s_hi; ++q) sum += tile[ol][il * 9 + r * 3 + q];
+            g4[(((int64_t)i * 4 + t) * 4 + u) * O + o] = from_f<T>(sum);
+        }
+    }
+    if (it.w_up4_fwd && kk == 9) {
+        T* __restrict__ f4 = (T*)it.w_up4_fwd;
+        for (int idx = threadIdx.x; idx < 4 * TO * 4 * TI; idx += 256) {  // [cls][o][a][b][i], i fastest
+            const int il = idx % TI, bq = (idx / TI) & 1, aq = (idx / (TI * 2)) & 1, ol = (idx / (TI * 4)) % TO, cls = idx / (TI * 4 * TO);
+            const int o = o0 + ol, i = i0 + il;
+            if (o >= O || i >= I) continue;
+            const int ph = cls >> 1, pw = cls & 1;
+            const int r_lo = ph == 0 ? (aq == 0 ? 0 : 1) : (aq == 0 ? 0 : 2), r_hi = ph == 0 ? (aq == 0 ? 0 : 2) : (aq == 0 ? 1 : 2);
+            const int s_lo = pw == 0 ? (bq == 0 ? 0 : 1) : (bq == 0 ? 0 : 2), s_hi = pw == 0 ? (bq == 0 ? 0 : 2) : (bq == 0 ? 1 : 2);
+            float sum = 0.f;
+            for (int r = r_lo; r <= r_hi; ++r)
+                for (int q = s_lo; q <= s_hi; ++q) sum += tile[ol][il * 9 + r * 3 + q];
+            f4[((((int64_t)cls * O + o) * 2 + aq) * 2 + bq) * I + i] = from_f<T>(sum);
+        }
+    }
     if (!wd) return;
     if (pair_o) {
         for (int idx = threadIdx.x; idx < TO * run / 2; idx += 256) {  // wd[i][flipped tap][o], o in pairs

@@ -932,13 +932,13 @@ class Engine:
                     it.first_block, it.Cout, it.Cin, it.ksize = blocks, c.cout, c.cin, c.k
                     if bias_out:
                         it.bias, it.bias_out = c.b.data_ptr(), bias_out
+                    if wd == c.wd.data_ptr() and c.wd4 is not None:       # an upsampling convolution's combined filters
+                        it.w_up4_dgrad, it.w_up4_fwd = c.wd4.data_ptr(), c.wf4.data_ptr()
                     blocks += ((c.cout + 31) // 32) * ((c.cin + 31) // 32)
                 raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
                 self._repack_table = (raw, len(entries), blocks)
             raw, n, blocks = self._repack_table
             call("vamd_repack_weights", _ptr(raw), n, blocks, self.dt, _stream())
-            for c in self.all_convs():
-                c.repack_up4()
             for layer in self.layers:
                 if isinstance(layer, _ResBlock):
                     layer.refresh_bias()
