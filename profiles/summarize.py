@@ -1,7 +1,8 @@
-"""Turns gpurun_out/collect (written by profiles/collect.sh) into the committed summaries:
-r2_train_step_kernel_stats.csv, r2_train_step_bench_line.json, r2_bench_lines.json (the three presets without a
-profiler attached), r2_pmc_tcc_traffic.csv (first line: hash of the kernel sources it was taken with) and
-r2_pmc_sq_summary.csv."""
+"""Turns gpurun_out/collect and gpurun_out/trace_<preset> (written by profiles/collect.sh) into the committed summaries:
+r3_bench_lines.json (the five presets and the graph-replayed butterfly step, no profiler attached),
+r3_pmc_tcc_traffic.csv (first line: hash of the kernel sources it was taken with), r3_pmc_sq_summary.csv, and per preset
+r3_<preset>_kernel_stats.csv + r3_<preset>_bench_line_profiled.json with the per-family tables of r3_kernel_families.md
+(--families writes those alone, from a run of profiles/trace_presets.sh)."""
 import collections
 import csv
 import glob
@@ -47,10 +48,6 @@ def write_traffic():
 
 
 def write_rest():
-    shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(HERE, ROUND + "_train_step_kernel_stats.csv"))
-    line = [ln for ln in open(os.path.join(SRC, "trace.log")) if ln.startswith("{")][-1]
-    open(os.path.join(HERE, ROUND + "_train_step_bench_line.json"), "w").write(line)
-
     sq, ns = counters("sq")
     names = sorted({c for v in sq.values() for c in v})
     with open(os.path.join(HERE, ROUND + "_pmc_sq_summary.csv"), "w", newline="") as f:
@@ -59,8 +56,9 @@ def write_rest():
         for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
             w.writerow([k, ns[k]] + [round(v.get(c, 0.0)) for c in names])
     with open(os.path.join(HERE, ROUND + "_bench_lines.json"), "w") as f:
-        for preset in ("butterfly", "flowers", "ffhq"):
+        for preset in ("butterfly", "flowers", "ffhq", "vqvaeunet", "ldm", "butterfly_graph"):
             f.write([ln for ln in open(os.path.join(SRC, f"bench_{preset}.json")) if ln.startswith("{")][-1])
+    write_family_tables(os.path.join(SRC, ".."))
     print("wrote summaries from", SRC)
 
 
