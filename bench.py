@@ -387,7 +387,7 @@ def main():
     if n:
         conv_ms += t
         ach = f / (t * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_ntw_mfma_kernel / conv_ntp_mfma_kernel / conv_nt8_kernel / conv_c64_halo_kernel <bf16> (persistent implicit-GEMM, forward + input gradient)",
+        roof = {"bound": "mfma", "kernel": "conv_ntw_mfma_kernel / conv_ntp_mfma_kernel / conv_c64_halo_kernel <bf16> (persistent implicit-GEMM, forward + input gradient)",
                 "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                 "traffic": measured_traffic("conv_ntp_mfma_kernel", "conv_ntw_mfma_kernel", "conv_c64_halo_kernel") if args.preset == "butterfly" and B == 64 else None,

@@ -122,14 +122,14 @@ SPLIT_CASES = [
     (7, 223, 111, 128, 128, 3, 2, 0),     # stride 2, ragged last tile
 ]
 
-# Shapes with enough tiles (>= 200) for the ping-pong kernel to take them as whole tiles without any scratch buffer.
+# Shapes with at least 200 tiles: every workgroup of the wide kernels walks whole tiles, several of them in a row.
 WIDE_CASES = [
-    (8, 128, 128, 64, 128, 3, 1, 0),      # 256 tiles of 512 x 128
+    (8, 128, 128, 64, 128, 3, 1, 0),      # 512 tiles of 256 x 128
     (4, 128, 128, 128, 256, 3, 1, 0),     # 256 tiles of 256 x 256 (reduction of 1152: the longest this tile serves)
     (17, 223, 111, 128, 128, 3, 2, 0),    # stride 2, 209 tiles, ragged last tile
-    (8, 128, 128, 128, 128, 1, 1, 0),     # 1 x 1: four K-tiles per tile, as many as the load ring has stages
-    (8, 128, 128, 64, 128, 1, 1, 0),      # two K-tiles per tile
-    (8, 128, 128, 32, 256, 1, 1, 0),      # one K-tile per tile
+    (8, 128, 128, 128, 128, 1, 1, 0),     # 1 x 1: two K-steps per tile (fewer than the load ring has stages)
+    (8, 128, 128, 64, 128, 1, 1, 0),      # one K-step per tile
+    (8, 128, 128, 32, 256, 1, 1, 0),      # half a K-step per tile
 ]
 
 
@@ -186,7 +186,7 @@ def test_conv_wide_tiles(case):
             call("vamd_conv2d_dgrad", C.byref(d), P(dyn), P(wd), P(addn), P(dx), P(ws), nb, S())
         assert relerr(dx.permute(0, 3, 1, 2), gx + add64) < TOL_OUT["bf16"], name
         outs[name] = (y, dx)
-        # bias-only forward and a plain (not accumulating) input gradient: the form the ping-pong kernel takes by default
+        # bias-only forward and a plain (not accumulating) input gradient: epilogues without a loaded term
         y0 = torch.full((B, Ho, Wo, Cout), 7.0, dtype=tdt, device=DEV)
         call("vamd_conv2d_fwd", C.byref(d), P(xn), P(wf), P(bias.to(DEV)), None, None, None, P(y0), S())
         assert relerr(y0.permute(0, 3, 1, 2), y64.detach() + bias.double()[None, :, None, None]) < TOL_OUT["bf16"], name
@@ -469,8 +469,6 @@ def test_conv_fwd_with_shortcut_source(case, dts):
     if dts == "bf16" and (Cin, Cout, k) == (64, 64, 3) and os.environ.get("VAMD_C64_HALO_MIN") == "1":
         assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2) == 0
         pytest.skip("the resident-filter kernel is forced for this shape; it has no second source")
-    if os.environ.get("VAMD_NT8_MIN") == "1" and lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2) == 0:
-        pytest.skip("the ping-pong kernel is forced for this shape; it has no second source")
     assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2) == 1
     assert lib.vamd_conv2d_fwd_short_supported(C.byref(d), Cin2 + 8) == 0
     x, x64 = rnd((B, Cin, H, W), tdt, gen)

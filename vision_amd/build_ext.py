@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libvision_amd.so")
 PROBE_LIB = os.path.join(OUT_DIR, "libvamd_probe.so")
-SOURCES = ["elementwise.hip", "norm.hip", "conv_direct.hip", "conv_api.hip", "conv_mfma.hip", "conv_nt8.hip", "conv_wgrad_halo.hip", "conv_thin.hip",
+SOURCES = ["elementwise.hip", "norm.hip", "conv_direct.hip", "conv_api.hip", "conv_mfma.hip", "conv_wgrad_halo.hip", "conv_thin.hip",
            "conv_thin_mfma.hip", "attention.hip", "vq.hip", "image.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -71,7 +71,7 @@ def build_variant(name, defines, force=False, verbose=True):
     """An experiment build under its own name and object directory; -DVAMD_ABLATE=n additionally gets the
     acknowledgement macro without which conv_mfma.hip refuses to compile an ablation."""
     defines = list(defines)
-    if any(d.startswith(("-DVAMD_ABLATE", "-DVAMD_NT8_ABLATE")) for d in defines):
+    if any(d.startswith("-DVAMD_ABLATE") for d in defines):
         defines.append("-DVAMD_TIMING_ONLY_BUILD")
     lib = os.path.join(OUT_DIR, f"libvision_amd_{name}.so")
     return _compile_and_link(SOURCES, lib, os.path.join(HERE, "build", "variant_" + name), defines, force, verbose)

@@ -20,7 +20,7 @@
 #include "conv_shapes.h"
 
 #ifndef VAMD_ABLATE
-#define VAMD_ABLATE 0        // 1..4, 10, 11 / 5..7 / 8: timing-only experiments on the wide / the 128-row / the weight-gradient kernel (results are wrong)
+#define VAMD_ABLATE 0        // 1..4, 10, 11 / 5..7 / 8 / 12: timing-only experiments on the wide / the 128-row / the weight-gradient kernel / every register epilogue (results are wrong)
 #endif
 #if VAMD_ABLATE != 0 && !defined(VAMD_TIMING_ONLY_BUILD)
 #error "VAMD_ABLATE variants compute wrong results: build them with `build_ext.py --variant NAME -DVAMD_ABLATE=n` (a separately named library), never into libvision_amd.so"
@@ -671,15 +671,18 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     // ---- staging: this thread copies piece `slot` of rows srow + 64*i
     const int srow = tid >> 3, slot = tid & 7;
     const int chunk = slot ^ (srow & 7);                 // logical piece held by this LDS slot
-    // filter rows: LDS row R of the wave half h = R / (BN/2), q = R % (BN/2) = 16*jc + i holds
-    // channel h*(BN/2) + (i>>2)*CPL + 4*jc + (i&3)
+    // filter rows: LDS row R of the wave half h = R / (BN/2), q = R % (BN/2) = 16*jc + i holds channel
+    // h*(BN/2) + chan_of(jc, i>>2) + (i&3): accumulator tile jc of lane group g = i>>2 starts at channel
+    // 64 (jc>>2) + 16 g + 4 (jc&3) of the wave's half, so that a lane's tiles jc = 4t .. 4t+3 are 16 consecutive
+    // channels and the four lane groups together one 64-channel run (the 128 bytes of a pixel that a store writes whole)
+    auto chan_of = [](int jc, int g) { return 64 * (jc >> 2) + 16 * g + 4 * (jc & 3); };
     int b_off[NPB], b_off2[TWO ? NPB : 1];
     bool b_ok[NPB];
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
         const int R = srow + 64 * i;
         const int h = R / (BN / 2), q = R - h * (BN / 2);
-        const int n = n0 + h * (BN / 2) + ((q & 15) >> 2) * CPL + 4 * (q >> 4) + (q & 3);
+        const int n = n0 + h * (BN / 2) + chan_of(q >> 4, (q & 15) >> 2) + (q & 3);
         b_ok[i] = n < N;
         b_off[i] = (b_ok[i] ? n : 0) * ldw;
         if constexpr (TWO) b_off2[i] = (b_ok[i] ? n : 0) * gp.Cin2;
@@ -816,8 +819,9 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
                         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][e], a[i][e], acc[j][i], 0, 0, 0);
         }
     };
-    // ---- outputs: lane (p = lane & 15, grp = lane >> 4) holds, per pixel tile, channels nb .. nb+CPL-1
-    const int nb = n0 + wn * (BN / 2) + fgrp * CPL;
+    // ---- outputs: lane (p = lane & 15, grp = lane >> 4) holds, per pixel tile, channels nb .. nb+15 in accumulator
+    // tiles 0 .. 3 (and nb+64 .. nb+79 in tiles 4 .. 7 of the 256-channel tile)
+    const int nb = n0 + wn * (BN / 2) + fgrp * 16;
     // Fused statistics: per-lane sums in registers, except for the 256-channel tile, whose 128
     // accumulators leave no room for 64 more: there every (pixel-wave row, channel) owns a slot
     // pair in LDS behind the stages, updated once per tile by the one lane that holds the
@@ -831,30 +835,44 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     float s1[STATS_REG ? CPL : 1], s2[STATS_REG ? CPL : 1];
 #pragma unroll
     for (int e = 0; e < (STATS_REG ? CPL : 1); ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    // accumulators start from the bias (alpha is 1 whenever a bias is given)
+    // accumulators start from the bias (alpha is 1 whenever a bias is given), kept in LDS: a load from global memory here
+    // would be younger than the stores of the tile just written, and waiting for it would wait for them
+    float* bias_lds = sred + (STATS_LDS ? 4 * BN * 2 : 0);                            // [BN]
+    for (int idx = tid; idx < BN; idx += 512) bias_lds[idx] = (ep.bias && n0 + idx < N) ? ep.bias[n0 + idx] : 0.f;
+    __syncthreads();
+    // (read by inline asm: behind a read the compiler knows to be an LDS read it waits for every pending direct-to-LDS load,
+    // and with them for the stores)
+    const uint32_t bias_addr = (uint32_t)(uintptr_t)LPTR(bias_lds + (nb - n0));
     auto init_acc = [&]() {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (ep.bias) {
-                const int n = nb + 4 * j;
-                if (n + 4 <= N) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(ep.bias + n);
-                    bv = f32x4_t{t4.x, t4.y, t4.z, t4.w};
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bv[r] = n + r < N ? ep.bias[n + r] : 0.f;
-                }
-            }
+            f32x4_t bv;
+            asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(bv) : "v"(bias_addr), "n"(4 * (64 * (j >> 2) + 4 * (j & 3))));
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = bv;
         }
     };
+    // The tile's stores go out as buffer stores, a fixed number per lane (NSTORE), so that the first wait of the next tile
+    // can leave exactly them in flight instead of standing still for their round trip to L2; not for fp32 outputs of a
+    // bf16 product and the fused normalise (their store counts differ: those keep the full wait).
+#ifdef VAMD_NOBUF
+    constexpr bool BUF = false;
+#else
+    constexpr bool BUF = !ACT;
+#endif
+    // LDS the transposing epilogue passes a row group through, two 1 KB regions per wave: with three stages, this wave's
+    // first two pixel slices of the stage just consumed (every wave is past the K-step's barrier, and only this wave's own
+    // direct-to-LDS loads write there again); with two stages, 2 KB of its own behind the bias
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LPTR(smem);
+    uint32_t xp_base = BN == 256 ? (uint32_t)(uintptr_t)LPTR(bias_lds + BN) + (uint32_t)wave * 2048u : 0u;
+    constexpr uint32_t XP_STRIDE = BN == 256 ? 1024u : 8192u;
+    constexpr int NSTORE = 4 * (4 * NT * (int)sizeof(T) / 16);
+    const bool relax = BUF && !ep.out_f32;
     auto write_tile = [&](int row_tile) {
         const int z = row_tile < m_tiles ? 0 : row_tile / m_tiles, mt = row_tile - z * m_tiles;   // one batch entry: no division
-        epilogue_rows<T, NT, STATS_REG, 0, 4 * NT, ACT>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc,
+        epilogue_rows<T, NT, STATS_REG, 0, 4 * NT, ACT, BUF>(acc, s1, s2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc,
                                                         (int64_t)z * strideC + yoff, (uint32_t)(mt * BM + wm * 64 + frow), nb,
-                                                        ep.act_scale, ep.act_shift, ep.act_slope, ep.raw);
+                                                        ep.act_scale, ep.act_shift, ep.act_slope, ep.raw, 0, xp_base, XP_STRIDE, ep.nt_store);
     };
 
     // the 256-channel tile: the lane's 32 channels in two halves, so that only 16 sums and one half's
@@ -865,9 +883,10 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
         float t1[16], t2[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
-        epilogue_rows<T, NT, STATS_LDS, (NT == 8 ? 16 * H : 0), (NT == 8 ? 16 : 4 * NT), ACT>(
+        epilogue_rows<T, NT, STATS_LDS, (NT == 8 ? 16 * H : 0), (NT == 8 ? 16 : 4 * NT), ACT, BUF>(
             acc, t1, t2, gp, ep.temb, ep.res, ep.res2, ep.alpha, ep.out_f32, yout, N, ldc, (int64_t)z * strideC + yoff,
-            (uint32_t)(mt * BM + wm * 64 + frow), nb, ep.act_scale, ep.act_shift, ep.act_slope, ep.raw);
+            (uint32_t)(mt * BM + wm * 64 + frow), nb, ep.act_scale, ep.act_shift, ep.act_slope, ep.raw, (NT == 8 ? 64 * H : 0),
+            xp_base, XP_STRIDE, ep.nt_store);
         if constexpr (STATS_LDS) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -878,7 +897,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
                 }
             }
             if (frow == 0) {
-                float* slot = sred + ((wm * BN) + wn * (BN / 2) + fgrp * CPL + 16 * H) * 2;
+                float* slot = sred + ((wm * BN) + (nb - n0) + 64 * H) * 2;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     slot[2 * e] += t1[e];
@@ -932,8 +951,12 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
                 if (k == nk - 1) {
                     write_tile_pieces(cur);
                     init_acc();
+                    // the next stage was issued before the tile's stores: they alone may stay in flight (for a K-step)
+                    if (relax) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTORE) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 buf ^= 1;
             }
@@ -957,6 +980,7 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
     Frag a0[4], b0[NT], a1[4], b1[NT];
     read_frags(0, 0, a0, b0);
     int buf = 0;
+    bool stores_behind = false;                            // the previous K-step ended with a tile's NSTORE buffer stores
     for (;;) {
         for (int k = 0; k < nk; ++k) {
             const int sbuf = buf >= 1 ? buf - 1 : 2;      // (buf + 2) % 3: read during the previous K-step
@@ -975,8 +999,12 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
 #if VAMD_ABLATE == 1 || VAMD_ABLATE == 3
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-            if (issue) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPA) : "memory");
+            // (after a tile's epilogue: issued behind the stage waited for are the tile's stores and this K-step's pixel
+            // loads; the stores get until the next K-step's wait, whose stage was issued behind them)
+            if (issue && stores_behind) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPA + NSTORE) : "memory");
+            else if (issue) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            stores_behind = false;
 #endif
 #if VAMD_ABLATE != 2 && VAMD_ABLATE != 3
             __builtin_amdgcn_s_barrier();
@@ -990,8 +1018,10 @@ conv_ntw_mfma_kernel(Gather gp, const T* __restrict__ x, const T* __restrict__ w
             }
             mma(a1, b1);
             if (last) {
+                xp_base = lds0 + (uint32_t)buf * STAGE + (uint32_t)wave_s * 1024u;
                 write_tile(cur);
                 init_acc();
+                stores_behind = relax;
             }
             buf = nbuf;
         }
@@ -1772,7 +1802,9 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // Grid of the persistent kernel: as many workgroups as fit the chip at once (2 or 3 per CU), a whole
 // number of column-tile groups, and row tiles spread evenly over them.
 static int ntp_row_groups(int row_tiles, int n_tiles, int per_cu) {
-    int rmax = 256 * per_cu / n_tiles;
+    // VAMD_NT_CUS: compute units the persistent kernels spread over (experiments: what a tile costs on a partly idle chip)
+    static const int cus = [] { const char* e = getenv("VAMD_NT_CUS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
+    int rmax = cus * per_cu / n_tiles;
     if (rmax < 1) rmax = 1;
     const int rounds = (row_tiles + rmax - 1) / rmax;
     return (row_tiles + rounds - 1) / rounds;             // workgroups per column tile; each walks `rounds` row tiles
@@ -1794,6 +1826,12 @@ static bool nt_wide(int BN, int64_t M, int batch, int n_tiles) {
     static const int min_tiles = [] { const char* e = getenv("VAMD_NT_WIDE_MIN"); return e ? atoi(e) : 1; }();
     if (BN != 128 || nt_classic() || force == 0) return false;
     return ((M + 255) / 256) * batch * n_tiles >= min_tiles;
+}
+
+// Non-temporal stores for outputs from VAMD_NT_STORE_MB megabytes on (see Epilogue::nt_store).
+static int nt_store_for(int64_t out_bytes) {
+    static const int mb = [] { const char* e = getenv("VAMD_NT_STORE_MB"); return e ? atoi(e) : 40; }();
+    return out_bytes >= (int64_t)mb << 20;
 }
 
 // The launch-timing records count ALGORITHMIC FLOPs: what the reference's operator does (2*M*N*K of the
@@ -1865,7 +1903,7 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
     }
     if constexpr (BN == 128) {
         if (nt_wide(BN, gp.M, batch, n_tiles)) {
-            constexpr int LDS_W = 3 * (256 * kRowBytes + BN * kRowBytes);
+            constexpr int LDS_W = 3 * (256 * kRowBytes + BN * kRowBytes) + BN * (int)sizeof(float);   // stages + the column tile's bias
             static bool configured_w = false;
             if (!configured_w) {
                 int rc = set_lds_limit(conv_ntw_mfma_kernel<T, BN, UP, false>, LDS_W, "conv_ntw_mfma");
@@ -1884,6 +1922,9 @@ static int launch_nt(const Gather& gp, const T* x, const T* w, int N, int ldw, i
                 blocks = plan_classes(256, 256 / n_tiles > 0 ? 256 / n_tiles : 1, &flops);
                 for (int c = 0; c < cs.ncls; ++c) cs.stats_off[c] = (int64_t)(cs.first_block[c] / n_tiles) * N * 2;
             }
+            Epilogue epw = ep;
+            epw.nt_store = nt_store_for((int64_t)gp.M * batch * (classes ? cs.ncls : 1) * ldc * (int64_t)sizeof(T));
+            const Epilogue& ep = epw;
             TimedLaunch timed(TIMED_NT, take_flops(flops), flops, st);
             if (ep.act_scale) {
                 if constexpr (UP == 0)
@@ -1949,9 +1990,11 @@ static bool nt_wide256(int N, int64_t M, int batch, size_t elem, int Ktot, bool 
 }
 
 template <typename T, int UP>
-static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep,
+static int launch_ntw256(const Gather& gp, const T* x, const T* w, int N, int ldw, int ldc, const Epilogue& ep_in,
                          void* y, int batch, int64_t sA, int64_t sB, int64_t sC, hipStream_t st) {
-    constexpr int LDS_W = 2 * (256 * kRowBytes + 256 * kRowBytes) + 4 * 256 * 2 * (int)sizeof(float);   // stages + statistics slots
+    Epilogue ep = ep_in;
+    ep.nt_store = nt_store_for((int64_t)gp.M * batch * ldc * (int64_t)sizeof(T));
+    constexpr int LDS_W = 2 * (256 * kRowBytes + 256 * kRowBytes) + 4 * 256 * 2 * (int)sizeof(float) + 256 * (int)sizeof(float) + 8 * 2048;   // stages + statistics slots + bias + the epilogue's transposing regions
     static bool configured = false;
     if (!configured) {
         int rc = set_lds_limit(conv_ntw_mfma_kernel<T, 256, UP, false>, LDS_W, "conv_ntw_mfma");
@@ -2216,12 +2259,6 @@ static int run_nt(const Gather& gp, const void* x, const void* w, int N, int ldw
         }
     }
     if (ep.pre_scale) return fail(VAMD_EUNSUPPORTED, "conv: only the resident-filter kernel normalises its input (ask vamd_conv2d_prenorm_supported)");
-    if constexpr (sizeof(T) == 2) {
-        if (!classes && nt8_applicable(gp, N, ldw, ldc, ep, batch)) {
-            const double fl = 2.0 * gp.M * N * gp.Ktot;
-            return launch_nt8(gp, x, w, N, ldw, ldc, ep, y, take_flops(fl), fl, st);
-        }
-    }
     if (classes) {                                        // class sets: stride-1 gathers without upsampling
         if (N <= 64) return launch_nt<T, 64, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
         return launch_nt<T, 128, false>(gp, (const T*)x, (const T*)w, N, ldw, ldc, ep, y, batch, sA, sB, sC, st, classes);
@@ -2265,13 +2302,6 @@ int conv_fwd_mfma_stats_parts(const ConvGeom& g, int dtype) {
     if (dtype == VAMD_BF16 && g.Cin == 64 && (g.Cout == 64 || g.Cout == 128) && g.k == 3 && g.stride == 1 && g.pad == 1 && !g.up) {
         int pwl, tw, th, nt;                              // as run_nt picks the resident-filter kernel
         if (c64_halo_shape(g.H, g.W, g.M, &pwl, &tw, &th, &nt)) return c64_halo_blocks(nt, g.Cout / 64) / (g.Cout / 64);
-    }
-    if (dtype == VAMD_BF16) {                             // as run_nt picks the ping-pong kernel
-        const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
-        // the question is asked for a launch that does sum statistics: any non-null pointer stands for its buffer
-        static float stats_wanted;
-        const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, &stats_wanted, (unsigned char*)g.scratch, g.scratch_bytes};
-        if (nt8_applicable(gp, g.Cout, gp.Ktot, g.Cout, ep, 1)) return nt8_stats_parts(gp, g.Cout, ep);
     }
     if (dtype == VAMD_BF16 && nt_wide256(g.Cout, g.M, 1, 2, g.k * g.k * g.Cin, g.up != 0)) return ntp_row_groups((int)((g.M + 255) / 256), g.Cout / 256, 1);
     const int BN = g.Cout <= 64 ? 64 : 128;               // as run_nt picks
@@ -2340,11 +2370,6 @@ bool conv_fwd_short_mfma_supported(const ConvGeom& g, int dtype, int Cin2) {
         const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
         const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
         if (nt_split_rows(gp, g.Cout, g.Cout, ep, 1, dtype == VAMD_BF16 ? 2 : 4) > 0) return false;
-    }
-    if (dtype == VAMD_BF16) {                             // likewise where the ping-pong kernel serves the plain conv
-        const Gather gp = make_gather(g.H, g.W, g.Cin, g.He, g.We, g.Ho, g.Wo, g.k, g.stride, g.pad, g.up, g.M);
-        const Epilogue ep{nullptr, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, (unsigned char*)g.scratch, g.scratch_bytes};
-        if (nt8_applicable(gp, g.Cout, gp.Ktot, g.Cout, ep, 1)) return false;
     }
     return nt_shape_ok(g.Cin, g.Cout, g.M, dtype);
 }
@@ -2930,6 +2955,8 @@ int bmm_nt_mfma(const void* A, const void* Bm, void* C, int batch, int M, int N,
     Gather gp = make_gather(1, M, Kc, 1, M, 1, M, 1, 1, 0, 0, M);
     gp.ldx = lda;
     Epilogue ep{nullptr, nullptr, nullptr, nullptr, alpha, out_f32, nullptr};
+    if ((int64_t)batch * M * ldc * (out_f32 || dtype != VAMD_BF16 ? 4 : 2) >= (1ll << 31))    // 32-bit byte offsets of the kernels' stores
+        return fail(VAMD_EUNSUPPORTED, "bmm_nt: output of %d x %d x %d elements exceeds the 2 GiB buffer-addressing limit", batch, M, ldc);
     if (dtype == VAMD_BF16)
         return run_nt<bf16_t>(gp, A, Bm, N, ldb, ldc, ep, C, batch, (int64_t)M * lda, (int64_t)N * ldb, (int64_t)M * ldc, st);
     return run_nt<float>(gp, A, Bm, N, ldb, ldc, ep, C, batch, (int64_t)M * lda, (int64_t)N * ldb, (int64_t)M * ldc, st);

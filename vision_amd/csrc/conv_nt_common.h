@@ -82,6 +82,10 @@ struct Epilogue {
     const float* pre_scale;
     const float* pre_shift;
     float pre_slope;
+    // Set by the launch code: the transposing epilogue's whole-line stores are non-temporal.  That keeps a large output from
+    // displacing the kernel's own input in L2, but a small one (which the next kernel would have found in the caches) is
+    // then read back from memory.
+    int nt_store;
 };
 
 // Up to four convolutions of one layer in one launch (the output-parity classes of a stride-2 input
@@ -162,13 +166,17 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 // re-initialised for the next tile anyway; the order of the additions is temb, res, res2.
 // Core: the four rows are given by the element offset of the lane's first channel (offs), the image
 // each belongs to (bimg, for the time embedding; ascending) and a validity flag.
-template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT, bool ACT = false>
+// BUF: the outputs (not the fp32 and fused-normalise forms) leave through buffer stores with 32-bit offsets from yout
+// (outputs below 2 GiB), a row past the tensor or a piece past the last channel as a store at an offset the resource's range
+// check drops: every lane issues exactly 4 * NP stores, so a caller can count them in a later s_waitcnt vmcnt.
+template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT, bool ACT = false, bool BUF = false>
 __device__ __forceinline__ void epilogue_rows_at(f32x4_t (&acc)[NT][4], float* s1, float* s2,
                                                  const float* temb, const void* res, const void* res2, float alpha,
                                                  int out_f32, void* yout, int N, int ldc, const int64_t (&offs)[4],
                                                  const uint32_t (&bimg)[4], const bool (&valid)[4], int nb,
                                                  const float* asc = nullptr, const float* ash = nullptr,
-                                                 float aslope = 0.f, void* raw = nullptr) {
+                                                 float aslope = 0.f, void* raw = nullptr, uint32_t xp_base = 0,
+                                                 uint32_t xp_stride = 0, int nt_store = 0) {
     static_assert(C0 % 8 == 0 && CW % 8 == 0 && C0 + CW <= 4 * NT, "whole 16-byte pieces of the lane's channels");
     constexpr int CH = 16 / (int)sizeof(T);               // channels per 16-byte piece of T: 8 (bf16) or 4
     constexpr int NP = CW / CH;                           // pieces per row and lane
@@ -292,6 +300,104 @@ __device__ __forceinline__ void epilogue_rows_at(f32x4_t (&acc)[NT][4], float* s
         }
         return;
     }
+    if constexpr (BUF) {
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(yout);
+        // bf16, 16 channels per lane: the four lanes 16 g + pixel hold the 64-channel run of one pixel (128 bytes, a cache
+        // line where rows are whole lines).  Written from where the MFMA left them, a store instruction touches 16 lines,
+        // 64 scattered bytes of each, and the output displaces the kernel's input from L2 on its way to memory.  Instead a
+        // row group's pieces pass through 2 KB of LDS owned by the wave (xp_base: two 1 KB regions xp_stride apart) and come
+        // back transposed: lane L stores 16-byte chunk L & 7 of pixel 8 h + (L >> 3), so that every store writes eight whole
+        // lines, and the stores are non-temporal.  LDS row = pixel, 128 bytes, chunk index XOR ((pixel >> 1) & 7): writes
+        // and reads are conflict-free.  By inline asm: behind an LDS access the compiler knows of it waits for every pending
+        // direct-to-LDS load.  LDS operations of one wave execute in order, so only the read results are waited for.
+        // 128-channel layer at 112 x 112 x 64: 334 -> 310 us with these addresses, of which 294 without any store.
+        constexpr bool XP = sizeof(T) == 2 && NP == 2;
+        if constexpr (XP) {
+            const int ln = (int)(threadIdx.x & 63);
+            const int pix = ln & 15, grp = ln >> 4;
+            const uint32_t wrow = xp_base + (uint32_t)(pix >> 3) * xp_stride + (uint32_t)(pix & 7) * 128u;
+            const uint32_t wa0 = wrow + (uint32_t)(((2 * grp) ^ ((pix >> 1) & 7)) << 4);
+            const uint32_t wa1 = wrow + (uint32_t)(((2 * grp + 1) ^ ((pix >> 1) & 7)) << 4);
+            const uint32_t ra0 = xp_base + (uint32_t)(ln >> 3) * 128u + (uint32_t)(((ln & 7) ^ ((ln >> 4) & 7)) << 4);
+            const uint32_t ra1 = xp_base + xp_stride + (uint32_t)(ln >> 3) * 128u + (uint32_t)(((ln & 7) ^ ((4 + (ln >> 4)) & 7)) << 4);
+            const int run0 = nb - grp * 16;                               // first channel of the wave's run
+            const int cb = run0 + (ln & 7) * 8;
+            const bool chunk_ok = cb < N && cb + 8 <= ldc;
+            const bool lines = nt_store && (ldc & 63) == 0 && (run0 & 63) == 0 && run0 + 64 <= N;   // whole, aligned lines only
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Vec16<T> ov[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) ov[p].v[e] = from_f<T>(acc[J0 + ((p * CH + e) >> 2)][i][e & 3]);
+                    if constexpr (STATS) {
+                        if (valid[i] && piece_ok[p]) {
+#pragma unroll
+                            for (int e = 0; e < CH; ++e) {
+                                const float q = to_f(ov[p].v[e]);
+                                s1[p * CH + e] += q;
+                                s2[p * CH + e] = fmaf(q, q, s2[p * CH + e]);
+                            }
+                        }
+                    }
+                }
+                const u32x4_t w0 = __builtin_bit_cast(u32x4_t, ov[0]), w1 = __builtin_bit_cast(u32x4_t, ov[1]);
+                // byte offset of the run of this lane's pixel, or an offset the range check drops; the storing lanes fetch it
+                // from a lane that holds their pixel (the output may be scattered, so it is not derived from the lane number)
+                const uint32_t rb = valid[i] ? (uint32_t)(offs[i] - grp * 16) * 2u : kNoLoad;
+                asm volatile("ds_write_b128 %0, %1" ::"v"(wa0), "v"(w0) : "memory");
+                asm volatile("ds_write_b128 %0, %1" ::"v"(wa1), "v"(w1) : "memory");
+                u32x4_t o0, o1;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(ra0) : "memory");
+                asm volatile("ds_read_b128 %0, %1" : "=v"(o1) : "v"(ra1) : "memory");
+                const uint32_t prb0 = (uint32_t)__builtin_amdgcn_ds_bpermute((ln >> 3) * 4, (int)rb);
+                const uint32_t prb1 = (uint32_t)__builtin_amdgcn_ds_bpermute((8 + (ln >> 3)) * 4, (int)rb);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1)::"memory");
+#if VAMD_ABLATE == 12       // timing only: every store is dropped by the range check
+                const uint32_t off0 = alpha == -7.25f ? prb0 : kNoLoad, off1 = alpha == -7.25f ? prb1 : kNoLoad;
+#else
+                const uint32_t off0 = chunk_ok ? prb0 + (uint32_t)(ln & 7) * 16u : kNoLoad;        // kNoLoad + 112 is still out of range
+                const uint32_t off1 = chunk_ok ? prb1 + (uint32_t)(ln & 7) * 16u : kNoLoad;
+#endif
+                if (lines) {
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (int)off0, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (int)off1, 0, 2);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, ry, (int)off0, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, ry, (int)off1, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);         // row by row: scheduled as one block, the rows' values are all live at once
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#if VAMD_ABLATE == 12       // timing only: every store is dropped by the range check
+                const bool ok = alpha == -7.25f;
+#else
+                const bool ok = valid[i] && piece_ok[p];
+#endif
+                Vec16<T> ov;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(acc[J0 + ((p * CH + e) >> 2)][i][e & 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), ry,
+                                                       (int)(ok ? (uint32_t)(offs[i] + p * CH) * (uint32_t)sizeof(T) : kNoLoad), 0, 0);
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) {
+                        const float q = ok ? to_f(ov.v[e]) : 0.f;
+                        s1[p * CH + e] += q;
+                        s2[p * CH + e] = fmaf(q, q, s2[p * CH + e]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);             // row by row: scheduled as one block, the rows' values are all live at once
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (!valid[i]) continue;
@@ -301,6 +407,9 @@ __device__ __forceinline__ void epilogue_rows_at(f32x4_t (&acc)[NT][4], float* s
             Vec16<T> ov;
 #pragma unroll
             for (int e = 0; e < CH; ++e) ov.v[e] = from_f<T>(acc[J0 + ((p * CH + e) >> 2)][i][e & 3]);
+#if VAMD_ABLATE == 12       // timing only: the epilogue computes its values and stores none of them
+            if (alpha == -7.25f)
+#endif
             *reinterpret_cast<Vec16<T>*>(reinterpret_cast<T*>(yout) + offs[i] + p * CH) = ov;
             if constexpr (STATS) {                        // statistics of the rounded values a later pass would read
 #pragma unroll
@@ -315,13 +424,14 @@ __device__ __forceinline__ void epilogue_rows_at(f32x4_t (&acc)[NT][4], float* s
 }
 
 // The same for rows m_first + 16*i of the GEMM (with the output scatter of a parity class, if any).
-template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT, bool ACT = false>
+template <typename T, int NT, bool STATS, int C0 = 0, int CW = 4 * NT, bool ACT = false, bool BUF = false>
 __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[NT][4], float* s1, float* s2, const Gather& gp,
                                               const float* temb, const void* res, const void* res2, float alpha,
                                               int out_f32, void* yout, int N, int ldc, int64_t zoff,
                                               uint32_t m_first, int nb, const float* asc = nullptr,
-                                              const float* ash = nullptr, float aslope = 0.f, void* raw = nullptr) {
-    nb += C0;
+                                              const float* ash = nullptr, float aslope = 0.f, void* raw = nullptr,
+                                              int dchan = C0, uint32_t xp_base = 0, uint32_t xp_stride = 0, int nt_store = 0) {
+    nb += dchan;                                       // first channel of accumulator tile C0 / 4 (C0 where a lane's channels are one run)
     int64_t offs[4];
     uint32_t bimg[4];
     bool valid[4];
@@ -342,15 +452,9 @@ __device__ __forceinline__ void epilogue_rows(f32x4_t (&acc)[NT][4], float* s1, 
         }
         offs[i] = zoff + orow * ldc + nb;
     }
-    epilogue_rows_at<T, NT, STATS, C0, CW, ACT>(acc, s1, s2, temb, res, res2, alpha, out_f32, yout, N, ldc, offs, bimg, valid, nb,
-                                                asc, ash, aslope, raw);
+    epilogue_rows_at<T, NT, STATS, C0, CW, ACT, BUF>(acc, s1, s2, temb, res, res2, alpha, out_f32, yout, N, ldc, offs, bimg, valid, nb,
+                                                     asc, ash, aslope, raw, xp_base, xp_stride, nt_store);
 }
-
-// Ping-pong kernel for the wide bf16 layers (conv_nt8.hip): 256 x 256 or 512 x 128 tiles, plain gathers only.
-bool nt8_applicable(const Gather& gp, int N, int ldw, int ldc, const Epilogue& ep, int batch);
-int nt8_stats_parts(const Gather& gp, int N, const Epilogue& ep);   // workgroups per column tile = rows of `stats`
-int launch_nt8(const Gather& gp, const void* x, const void* w, int N, int ldw, int ldc, const Epilogue& ep, void* y,
-               double flops, double executed, hipStream_t st);
 
 // Weight gradient with the gradient tile resident in registers (conv_wgrad_halo.hip): 3 x 3 / stride 1 layers whose
 // channel counts are small multiples of 64, bf16.  One partial product [Cout][9][Cin] (+ [Cout] bias sums) per slice.
