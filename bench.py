@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the training step into a HIP graph (vision_amd.graphed) and time its replays; the per-launch "
                          "roofline figures are then taken over 10 eager steps before the capture")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="keep backward's weight-gradient kernels on the main stream in every step (kernel profiles in which "
+                         "no two kernels overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--sample-steps", type=int, default=None,
@@ -288,6 +291,8 @@ def main():
     dp = DataParallel(model)
     trace("parameters and buffers broadcast")
     eng = model._ensure_engine()
+    if args.one_stream:
+        eng.side_wgrad = False
     opt = model.configure_optimizers()[0][0]
 
     gen = torch.Generator(device="cpu").manual_seed(rank)
@@ -359,10 +364,25 @@ def main():
     # ---- the same steps again (launch by launch, also after --graph) with HIP events recorded inside the library on the
     # launch stream, directly around every MFMA convolution launch: the roofline of the dominant kernel.
     # VAMD_BENCH_LAYERS=1 adds per-call events in the engine for a per-layer table.
+    # In the timed steps backward's weight-gradient kernels run on a second stream, beside the input-gradient chain and
+    # its normalisation passes; a kernel timed while another one shares the chip says little about the kernel.  So the
+    # instrumented steps keep everything on one stream (kernels one at a time), and a few steps of that kind WITHOUT the
+    # events are timed first: `ms_per_step_one_stream` beside `ms_per_step` is what the second stream buys.
     layers = bool(os.environ.get("VAMD_BENCH_LAYERS"))
     prof = []                 # (kind, flops, start_event, end_event, shape) per MFMA conv call
     n_inst = min(args.steps, 20)
     stepper = None
+    two_streams = bool(getattr(eng, "side_wgrad", False))
+    one_stream_ms = None
+    if two_streams:
+        eng.side_wgrad = False
+        step(args.warmup + args.steps)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(n_inst):
+            step(args.warmup + args.steps + i)
+        fence()
+        one_stream_ms = 1e3 * (time.perf_counter() - t1) / n_inst
     lib.vamd_launch_timing(1)
     t1 = time.perf_counter()
     for i in range(n_inst):
@@ -372,6 +392,8 @@ def main():
     inst_ms = 1e3 * (time.perf_counter() - t1) / n_inst
     eng.profile = None
     lib.vamd_launch_timing(0)
+    if two_streams:
+        eng.side_wgrad = True
 
     def timed(kind):
         ms, fl, ex = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
@@ -399,7 +421,9 @@ def main():
                 "executed_frac": round(fx / (t * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}
     if roof is not None:
         roof["measured_over"] = (f"{n_inst} steps issued right after the timed ones with the library's per-launch HIP events on "
-                                 f"({inst_ms:.3f} ms per step with the events)")
+                                 f"({inst_ms:.3f} ms per step with the events)"
+                                 + (" and every kernel on one stream (in the timed steps the weight-gradient kernels run on a "
+                                    "second stream beside these launches)" if two_streams else ""))
     f, t, n, fx = timed(1)
     if n:
         conv_ms += t
@@ -415,6 +439,9 @@ def main():
                 str(shape), n, t / n, f / (t * 1e-3) / 1e12, 100 * t / sum(v[1] for v in per_shape.values())), file=sys.stderr)
     extra["mfma_conv_ms_per_step"] = round(conv_ms / n_inst, 3)
     extra["ms_per_step_with_launch_events"] = round(inst_ms, 3)
+    extra["weight_gradient_stream"] = two_streams
+    if one_stream_ms is not None:
+        extra["ms_per_step_one_stream"] = round(one_stream_ms, 3)
     # host time to issue a step's launches vs the step's wall time: the step is device-bound while the first
     # stays below the second
     extra["host_issue_ms_per_step"] = round(1e3 * host_free, 3)

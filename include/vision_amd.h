@@ -34,6 +34,11 @@ const char* vamd_last_error(void);
 /* Library / ABI version, and whether the MFMA path is compiled in. */
 int vamd_version(void);
 
+/* Stream plumbing, no counterpart in the reference (torch's autograd engine orders its streams itself): `waiter`
+ * executes nothing more until all work queued on `signaller` before this call has finished.  The engine forks the weight
+ * gradients of backward onto a second stream with it and joins them at the end. */
+int vamd_stream_wait(void* waiter, void* signaller);
+
 /* Benchmark aid, no counterpart in the reference.  vamd_launch_timing(1) makes the MFMA
  * convolution launchers record a HIP event pair around every kernel launch (on the stream of the
  * launch) and forgets earlier records; vamd_launch_timing(0) stops recording.

@@ -316,6 +316,6 @@ def test_bench_with_a_captured_step():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["graph_replay"] is True and line["value"] > 0 and line["steps"] == 4
-    assert 0 < line["host_issue_ms_per_step"] < 1.0, line["host_issue_ms_per_step"]
+    assert 0 < line["host_issue_ms_per_step"] < 2.0, line["host_issue_ms_per_step"]
     assert line["roofline"]["launches"] > 0 and "per-launch HIP events" in line["roofline"]["measured_over"]
     assert 0 < line["final_loss"] < 5

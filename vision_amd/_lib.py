@@ -108,6 +108,7 @@ SIGNATURES = {
     "vamd_repack_weights": (_i, [_p, _i, C.c_longlong, _i, _p]),
     "vamd_unpack_wgrad": (_i, [_p, _p, _i, _i, _i, _p]),
     "vamd_stats_chunks": (_i, [_l, _i]),
+    "vamd_stream_wait": (_i, [_p, _p]),
     "vamd_chan_stats": (_i, [_p, _p, _i, _l, _i, _i, _p]),
     "vamd_norm_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _l, _i, _i, _p]),
     "vamd_bn_finalize": (_i, [_p, _i, _i, _l, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _p, _p, _p]),

@@ -888,6 +888,34 @@ extern "C" {
 const char* vamd_last_error(void) { return g_err; }
 int vamd_version(void) { return 1; }
 
+// `waiter` runs nothing more until everything `signaller` has been given so far is done (an event recorded on one, waited
+// for on the other).  Events come from a per-device ring and are reused: a wait refers to the record made just before it.
+int vamd_stream_wait(void* waiter, void* signaller) {
+    constexpr int kRing = 256, kDevs = 64;
+    static hipEvent_t ring[kDevs][kRing];
+    static int next[kDevs];
+    static std::mutex mu;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kDevs) return fail((int)e, "vamd_stream_wait: hipGetDevice failed or device %d out of range", dev);
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        int& n = next[dev];
+        if (!ring[dev][n]) {
+            e = hipEventCreateWithFlags(&ring[dev][n], hipEventDisableTiming);
+            if (e != hipSuccess) return fail((int)e, "vamd_stream_wait: hipEventCreateWithFlags failed: %s", hipGetErrorString(e));
+        }
+        ev = ring[dev][n];
+        n = (n + 1) % kRing;
+    }
+    e = hipEventRecord(ev, as_stream(signaller));
+    if (e != hipSuccess) return fail((int)e, "vamd_stream_wait: hipEventRecord failed: %s", hipGetErrorString(e));
+    e = hipStreamWaitEvent(as_stream(waiter), ev, 0);
+    if (e != hipSuccess) return fail((int)e, "vamd_stream_wait: hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int vamd_launch_timing(int enable) {
     std::lock_guard<std::mutex> lk(g_timed_mu);
     g_timed_on = enable != 0;

@@ -10,6 +10,7 @@ Layouts: activations NHWC in the compute dtype (bf16 or fp32); parameters stay f
 [Cout][Cin][kh][kw] layout inside one flat arena (so state_dict()/safetensors interchange with
 the reference), with packed compute-dtype copies refreshed after every optimiser step.
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -33,10 +34,14 @@ def _ptr(t: Optional[torch.Tensor]):
 _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
 
 
+_stream_override = None      # raw handle of the second stream while one of Engine.side_section's blocks runs
+
+
 def _stream():
-    """The current HIP stream's handle.  (torch.cuda.current_stream().cuda_stream builds a Stream object through several
-    layers of device look-ups, ~8 us a call; a step makes ~400 of them.)"""
-    return _raw_stream(_cur_device())
+    """The HIP stream the library's launches go to: the current stream's handle, or the engine's second stream inside a
+    side section.  (torch.cuda.current_stream().cuda_stream builds a Stream object through several layers of device
+    look-ups, ~8 us a call; a step makes ~400 of them.)"""
+    return _stream_override if _stream_override is not None else _raw_stream(_cur_device())
 
 
 # a BatchNorm + LeakyReLU in front of a convolution applied inside the convolution's forward and weight-gradient kernels
@@ -233,12 +238,17 @@ class _Conv:
     def wgrad(self, dy, x, bias=True, pre=None):
         """Weight gradient into the arena; with bias=True the bias gradient (column sums of dy)
         comes out of the same launch.  pre: as in fwd()."""
+        with self.eng.side_section(dy, x, *(pre[:2] if pre is not None else ())):
+            self._wgrad(dy, x, bias, pre)
+
+    def _wgrad(self, dy, x, bias, pre):
         B, H, W, _ = x.shape
         gb = _ptr(self.gb) if bias else None
         ev = self._timed(2, B, H, W)
         sp = self.plan(B, H, W)
         nbytes = sp.wgrad_ws
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+        self.eng.side_keep(ws)
         if pre is not None:
             call("vamd_conv2d_wgrad_prenorm_oihw", sp.ref, _ptr(dy), _ptr(x), _ptr(pre[0]), _ptr(pre[1]), pre[2], _ptr(self.gw),
                  gb, _ptr(ws), nbytes, _stream())
@@ -281,12 +291,13 @@ class _QKV(_Conv):
         return [(c, self.wd.data_ptr() + j * Cc * self.wd.element_size(), 3 * Cc, self.b.data_ptr() + j * Cc * 4)
                 for j, c in enumerate(self.parts)]
 
-    def wgrad(self, dy, x, bias=True, pre=None):
+    def _wgrad(self, dy, x, bias, pre):
         B, H, W, _ = x.shape
         ev = self._timed(2, B, H, W)
         sp = self.plan(B, H, W)
         nbytes = sp.wgrad_ws
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+        self.eng.side_keep(ws)
         call("vamd_conv2d_wgrad_oihw_split3", sp.ref, _ptr(dy), _ptr(x), C.byref(self._dw3), C.byref(self._db3) if bias else None,
              _ptr(ws), nbytes, _stream())
         if ev is not None:
@@ -322,6 +333,10 @@ FUSE_EVAL_NORM = os.environ.get("VAMD_EVAL_FUSE", "1") != "0"
 FUSE_ATTENTION = os.environ.get("VAMD_ATTN_FUSE", "0") != "0"
 # backward: the gradients of every block's time-embedding projection in two launches at the end instead of two per block
 BATCH_TEMB_BWD = os.environ.get("VAMD_TEMB_BWD_MULTI", "1") != "0"
+# backward: weight gradients (with their reduce kernels) on a second stream.  Nothing on the input-gradient chain waits for
+# them, so they run beside its memory-bound normalisation passes and fill the gaps between its dependent launches; they are
+# joined before backward returns.  A gradient bucket is handed to the exchange behind both streams' work so far.
+SIDE_WGRAD = os.environ.get("VAMD_SIDE_WGRAD", "1") != "0"
 
 
 class _Norm:
@@ -509,15 +524,18 @@ class _ResBlock:
         # conv2 and shortcut share dy; their bias gradients are the same column sums of dy (copied: letting the shortcut's
         # weight-gradient launch form them again costs more than the copy launch, 19.29 vs 19.17 ms on the 224 x 224 step)
         # a2 is None where conv2 normalises h1 itself (forward above); likewise a1 / x for conv1
-        if a2 is None:
-            self.conv2.wgrad(dy, h1, pre=(coef2[0], coef2[1], self.bn2.slope))
-        else:
-            self.conv2.wgrad(dy, a2)
+        # (one side section for the weight gradients that read dy: every section costs the host an event record and a wait)
+        with e.side_section(dy, h1, a2, x, coef2, torch_ops=self.short is not None):
+            if a2 is None:
+                self.conv2._wgrad(dy, h1, True, (coef2[0], coef2[1], self.bn2.slope))
+            else:
+                self.conv2._wgrad(dy, a2, True, None)
+            if self.short is not None:
+                self.short.gb.copy_(self.conv2.gb)         # behind conv2's weight-gradient launch, wherever that runs
+                self.short._wgrad(dy, x, False, None)
         da2 = self.conv2.dgrad(dy, h1.shape)
         dxs = dy
         if self.short is not None:
-            self.short.gb.copy_(self.conv2.gb)
-            self.short.wgrad(dy, x, bias=False)
             dxs = self.short.dgrad(dy, x.shape) if need_dx else None
         # d(projected temb)[b][c] = sum over pixels of dh1; conv1 bias gradient = its sum over b: both
         # come out of the BatchNorm backward's statistics pass (dh1 is affine in the summed terms)
@@ -843,6 +861,8 @@ class Engine:
         self._repack_table = None
         self.drop_generator = None
         self.profile = None               # list -> receives (kind, flops, start, end) per MFMA conv launch
+        self.side_wgrad = SIDE_WGRAD        # weight gradients of backward on a second stream (see SIDE_WGRAD)
+        self._side_stream, self._side_on, self._side_keep = None, False, []
         self.debug_taps = None            # dict -> receives (output, folded skip) per layer (diagnostics)
         self._tproj_cache, self.tproj_for, self.tproj_src = {}, {}, None
         self._tbwd_cache, self.tbwd_for = {}, {}
@@ -1059,6 +1079,47 @@ class Engine:
             tape.append(("end", (h,)))
         return out
 
+    @contextlib.contextmanager
+    def side_section(self, *tensors, torch_ops=False):
+        """Inside backward with the second stream on: the library launches of the block go to that stream, behind everything
+        the main stream has been given so far.  `tensors` (what the block reads) and whatever the block passes to
+        side_keep() (workspaces it allocates: they come from the main stream's pool) stay referenced until the streams are
+        joined, so the allocator cannot hand their memory to a later main-stream tensor.  torch_ops: the block calls torch
+        operators or collectives, so torch's current stream is switched too (a few microseconds of host time more).
+        Otherwise a no-op."""
+        global _stream_override
+        if not self._side_on:
+            yield
+            return
+        side = self._side_stream
+        call("vamd_stream_wait", self._side_raw, _raw_stream(_cur_device()))
+        self._side_keep.extend(tensors)
+        if torch_ops:
+            with torch.cuda.stream(side):
+                yield
+            return
+        _stream_override = self._side_raw
+        try:
+            yield
+        finally:
+            _stream_override = None
+
+    def side_keep(self, t):
+        if self._side_on and t is not None:
+            self._side_keep.append(t)
+
+    def _side_begin(self, device):
+        self._side_on = bool(self.side_wgrad) and device.type == "cuda"
+        if self._side_on and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=device)
+            self._side_raw = self._side_stream.cuda_stream
+
+    def _side_join(self):
+        if self._side_on:
+            call("vamd_stream_wait", _raw_stream(_cur_device()), self._side_raw)
+            self._side_on = False
+        self._side_keep.clear()
+
     def backward(self, tape: list, dout):
         """dout: gradient of the NHWC prediction.  Writes every parameter gradient into the flat
         gradient arena (overwriting), returns nothing (the network input needs no gradient)."""
@@ -1067,10 +1128,12 @@ class Engine:
         red = self.reducer
         if red is not None:
             red.begin()
+        self._side_begin(dout.device)
         self.end.wgrad(dout, h_end)
         g = self.end.dgrad(dout, h_end.shape)
         if red is not None:
-            red.layer_done(self._lows["End"])
+            with self.side_section(torch_ops=True):   # a bucket goes out behind both streams' work so far
+                red.layer_done(self._lows["End"])
         nd, nm = self.n_down, self.n_mid
         n_up = len(self.layers) - nd - nm
         B = dout.shape[0]
@@ -1092,7 +1155,8 @@ class Engine:
                 dskip[nd - 1 - j] = g_in
             g = g_in
             if red is not None and self._lows[layer.spec.prefix] is not None:
-                red.layer_done(self._lows[layer.spec.prefix])
+                with self.side_section(torch_ops=True):
+                    red.layer_done(self._lows[layer.spec.prefix])
         tag, (emb, t1, temb) = tape.pop()
         assert tag == "temb"
         if tbwd is not None:
@@ -1101,7 +1165,9 @@ class Engine:
         self.lin2.bwd(t1, dtemb, dx=dt1)
         self.lin1.bwd(emb, dt1, dx=None)
         if red is not None:
-            red.finish()
+            with self.side_section(torch_ops=True):
+                red.finish()
+        self._side_join()
         self.attach_grads()
 
     def attach_grads(self):
