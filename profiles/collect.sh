@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/collect
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python -c "import sys; sys.path.insert(0, '$ROOT'); from vision_amd import _lib; print(_lib.source_hash())" > $OUT/source_hash.txt
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-sampling"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-sampling --one-stream"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- $BENCH --steps 1 --warmup 1 > $OUT/fetch.log 2>&1
 echo "fetch done"
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- $BENCH --steps 1 --warmup 1 > $OUT/write.log 2>&1
@@ -21,6 +21,7 @@ echo "write done"
 (cd $ROOT && timeout -k 10 300 python bench.py --preset vqvaeunet > $OUT/bench_vqvaeunet.json 2> $OUT/bench_vqvaeunet.err) && echo "first stage done"
 (cd $ROOT && timeout -k 10 300 python bench.py --preset ldm > $OUT/bench_ldm.json 2> $OUT/bench_ldm.err) && echo "ldm done"
 (cd $ROOT && timeout -k 10 300 python bench.py --graph --no-cpu-baseline --no-sampling > $OUT/bench_butterfly_graph.json 2> $OUT/bench_butterfly_graph.err) && echo "graph replay done"
+(cd $ROOT && timeout -k 10 300 python bench.py --one-stream --no-cpu-baseline --no-sampling > $OUT/bench_butterfly_one_stream.json 2> $OUT/bench_butterfly_one_stream.err) && echo "one stream done"
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/sq -- $BENCH --steps 1 --warmup 1 > $OUT/sq.log 2>&1
 echo "sq done"
 bash $ROOT/profiles/trace_presets.sh

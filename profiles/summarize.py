@@ -56,7 +56,7 @@ def write_rest():
         for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
             w.writerow([k, ns[k]] + [round(v.get(c, 0.0)) for c in names])
     with open(os.path.join(HERE, ROUND + "_bench_lines.json"), "w") as f:
-        for preset in ("butterfly", "flowers", "ffhq", "vqvaeunet", "ldm", "butterfly_graph"):
+        for preset in ("butterfly", "flowers", "ffhq", "vqvaeunet", "ldm", "butterfly_graph", "butterfly_one_stream"):
             f.write([ln for ln in open(os.path.join(SRC, f"bench_{preset}.json")) if ln.startswith("{")][-1])
     write_family_tables(os.path.join(SRC, ".."))
     print("wrote summaries from", SRC)
@@ -153,6 +153,8 @@ def write_family_tables(root):
         d = json.loads(line)
         # the profiled process runs the warm-up steps, the timed steps and the instrumented steps that follow them
         steps = d["warmup"] + d["steps"] + min(d["steps"], 20) + (3 if d.get("graph_replay") else 0)
+        if d.get("weight_gradient_stream"):
+            steps += 1 + min(d["steps"], 20)            # the one-stream steps timed before the instrumented ones
         tables.append(family_table(preset, dst, line, steps))
     with open(os.path.join(HERE, f"{ROUND}_kernel_families.md"), "w") as f:
         f.write("\n".join(tables))

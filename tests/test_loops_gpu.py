@@ -271,3 +271,39 @@ def test_graph_replayed_steps_equal_eager_steps():
     assert torch.equal(l0, l1) and torch.equal(t0, t1) and torch.equal(l1, t1)
     assert torch.equal(b0, b1) and torch.equal(n0, n1)
     assert torch.equal(p0, p1)
+
+
+def test_weight_gradients_on_a_second_stream_change_no_bit():
+    """Backward with its weight gradients on the engine's second stream (the default) against every kernel on one stream:
+    identical gradients after one step, identical losses and parameters after four optimiser steps on changing batches;
+    the second stream is joined when backward returns (nothing is left referenced for it)."""
+    import vision_amd
+    cfg = dict(name="ddpm", input_channels=3, learning_rate=1e-3, manual_seed=42, h_dims=[3, 32, 64, 64], down_index=[0, 1, 1, 1],
+               attn_res=[8], with_conv=True, dropout=0.1, latent_dim=64, sampling_period=1, weight_decay=1e-3,
+               diffusion_steps=4, scheduler_gamma=0.9, patch_size=32, grid=2)
+    gen = torch.Generator().manual_seed(5)
+    batches = [(torch.rand((4, 3, 32, 32), generator=gen).to(DEV), torch.zeros(4, dtype=torch.int64, device=DEV)) for _ in range(4)]
+    out = []
+    for two_streams in (True, False):
+        torch.manual_seed(7)
+        model = vision_amd.get_model("ddpm", cfg, compute_dtype="bf16").to(DEV).train()
+        (opt,), _ = model.configure_optimizers()
+        eng = model._ensure_engine()
+        eng.side_wgrad = two_streams
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        losses, first = [], None
+        for i, b in enumerate(batches):
+            loss = model.training_step(b, i)
+            loss.backward()
+            assert not eng._side_on and not eng._side_keep
+            if first is None:
+                torch.cuda.synchronize()
+                first = eng.flat_g.clone()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        assert (eng._side_stream is not None) == two_streams
+        out.append((first, torch.stack(losses).cpu(), eng.flat_p.clone()))
+    (g0, l0, p0), (g1, l1, p1) = out
+    assert torch.equal(g0, g1) and torch.equal(l0, l1) and torch.equal(p0, p1)

@@ -14,6 +14,7 @@ import contextlib
 import ctypes as C
 import math
 import os
+import threading
 from typing import Dict, List, Optional
 
 import torch
@@ -34,14 +35,19 @@ def _ptr(t: Optional[torch.Tensor]):
 _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
 
 
-_stream_override = None      # raw handle of the second stream while one of Engine.side_section's blocks runs
+class _StreamOverride(threading.local):
+    raw = None               # raw handle of the second stream while one of Engine.side_section's blocks runs in this thread
+
+
+_override = _StreamOverride()
 
 
 def _stream():
     """The HIP stream the library's launches go to: the current stream's handle, or the engine's second stream inside a
     side section.  (torch.cuda.current_stream().cuda_stream builds a Stream object through several layers of device
     look-ups, ~8 us a call; a step makes ~400 of them.)"""
-    return _stream_override if _stream_override is not None else _raw_stream(_cur_device())
+    raw = _override.raw
+    return raw if raw is not None else _raw_stream(_cur_device())
 
 
 # a BatchNorm + LeakyReLU in front of a convolution applied inside the convolution's forward and weight-gradient kernels
@@ -1087,7 +1093,6 @@ class Engine:
         joined, so the allocator cannot hand their memory to a later main-stream tensor.  torch_ops: the block calls torch
         operators or collectives, so torch's current stream is switched too (a few microseconds of host time more).
         Otherwise a no-op."""
-        global _stream_override
         if not self._side_on:
             yield
             return
@@ -1098,11 +1103,11 @@ class Engine:
             with torch.cuda.stream(side):
                 yield
             return
-        _stream_override = self._side_raw
+        _override.raw = self._side_raw
         try:
             yield
         finally:
-            _stream_override = None
+            _override.raw = None
 
     def side_keep(self, t):
         if self._side_on and t is not None:

@@ -156,10 +156,12 @@ class VQUNetEngine(Engine):
         red = self.reducer
         if red is not None:
             red.begin()
+        self._side_begin(dout.device)                 # weight gradients on the second stream, as in Engine.backward
         self.end.wgrad(dout, h_end)
         g = self.end.dgrad(dout, h_end.shape)
         if red is not None:
-            red.layer_done(self._lows["End"])
+            with self.side_section(torch_ops=True):
+                red.layer_done(self._lows["End"])
         ne, n = self.n_enc, len(self.layers)
         dskip: Dict[int, torch.Tensor] = {}
         for i in range(n - 1, -1, -1):
@@ -172,11 +174,14 @@ class VQUNetEngine(Engine):
             if 0 <= j < ne:
                 dskip[ne - 1 - j] = g                   # the decoder input was a sum: its gradient reaches the skip too
             if red is not None and self._lows[layer.spec.prefix] is not None:
-                red.layer_done(self._lows[layer.spec.prefix])
+                with self.side_section(torch_ops=True):
+                    red.layer_done(self._lows[layer.spec.prefix])
             if i == ne:
                 g = self._quantize_bwd(tape, g, dskip.pop(ne - 1), g_vq)
         if red is not None:
-            red.finish()
+            with self.side_section(torch_ops=True):
+                red.finish()
+        self._side_join()
         self.attach_grads()
 
     def _quantize_bwd(self, tape, g_out, g_skip, g_vq):
