@@ -303,7 +303,7 @@ def test_weight_gradients_on_a_second_stream_change_no_bit():
             opt.step()
             losses.append(loss.detach().clone())
         torch.cuda.synchronize()
-        assert (eng._side_stream is not None) == two_streams
+        assert (eng._side_streams is not None) == two_streams
         out.append((first, torch.stack(losses).cpu(), eng.flat_p.clone()))
     (g0, l0, p0), (g1, l1, p1) = out
     assert torch.equal(g0, g1) and torch.equal(l0, l1) and torch.equal(p0, p1)

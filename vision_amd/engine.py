@@ -109,7 +109,9 @@ class _Conv:
             d = ConvDesc(B, H, W, self.cin, self.cout, self.k, self.stride, self.pad, int(self.up),
                          self.eng.dt, self.eng.algo)
             if self.eng.scratch is not None:      # lets the wide kernels split tiles between workgroups
-                d.scratch, d.scratch_bytes = self.eng.scratch.data_ptr(), self.eng.scratch.numel()
+                # (a convolution that may run beside another one on a stream of its own has its own buffer)
+                buf = self.eng.scratch_aux if getattr(self, "own_scratch", False) else self.eng.scratch
+                d.scratch, d.scratch_bytes = buf.data_ptr(), buf.numel()
             self._descs[key] = d
         return d
 
@@ -234,6 +236,7 @@ class _Conv:
             return dx
         nbytes = sp.dgrad_ws
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device) if nbytes else None
+        self.eng.side_keep(ws)
         ev = self._timed(1, B, H, W)
         call("vamd_conv2d_dgrad", sp.ref, _ptr(dy), _ptr(self.wd), _ptr(add), _ptr(dx), _ptr(ws),
              nbytes, _stream())
@@ -463,6 +466,8 @@ class _ResBlock:
         # the 1x1 shortcut: an nn.Conv2d (DDPM) or a channel-wise nn.Linear wrapped in a module (the VQ-VAE-UNet blocks);
         # both store [Cout][Cin] row-major
         self.short = _Conv(eng, p + eng.shortcut_key, spec.cin, spec.cout, 1) if spec.cin != spec.cout else None
+        if self.short is not None:
+            self.short.own_scratch = True            # its forward and input gradient run beside conv1's / conv2's
         self.convs = [c for c in (self.conv1, self.conv2, self.short) if c is not None]
         self._gb_stale = False                   # conv1's bias gradient holds an eval-mode value
         # nn.Dropout's 1/(1-p) stays an fp32 kernel argument; the mask tensor holds exact 0/1 values
@@ -491,11 +496,19 @@ class _ResBlock:
         tproj = self.eng.tproj_for.get(id(self)) if (self.temb is not None and self.eng.tproj_src is temb) else None
         if tproj is None and self.temb is not None:
             tproj = self.temb.fwd(temb)
+        # the 1x1 shortcut reads x alone: issued now on its own stream, it runs (memory-bound) beside conv1 and the
+        # normalisation in front of conv2, whose epilogue adds it; main waits for it right before that launch
+        e = self.eng
+        sc = x
+        early = self.short is not None and not (FUSE_SHORTCUT and not fuse and not pre2)
+        if early:
+            with e.side_section(x, lane=1):
+                sc = self.short.fwd(x)
         if fuse:
-            sc = self.short.fwd(x) if self.short is not None else x
             # no tape: h1 itself is never needed, its normalised form comes straight out of conv1
             got = self.conv1.fwd_act(a1, self.bn2, temb=tproj)
             a2 = got[0] if got is not None else self.bn2.fwd(self.conv1.fwd(a1, temb=tproj), False)[0]
+            e.side_wait(1)
             got = self.conv2.fwd_act(a2, next_norm, res=sc, res2=res2, want_raw=True) if next_norm is not None else None
             if got is None:
                 return self.conv2.fwd(a2, res=sc, res2=res2)
@@ -511,14 +524,16 @@ class _ResBlock:
         a2, coef2 = self.bn2.fwd(h1, training, mask, self.mask_scale, apply=not pre2)
         y = None
         if pre2:
-            sc = self.short.fwd(x) if self.short is not None else x
+            e.side_wait(1)
             y = self.conv2.fwd(h1, res=sc, res2=res2, want_stats=want_stats, pre=(coef2[0], coef2[1], self.bn2.slope))
         # the 1x1 shortcut as extra reduction steps of conv2: measured +0.3 % on the training step and
         # -2.5 % on 16-image sampling batches against the two-launch form, so it is opt-in
         if y is None and self.short is not None and FUSE_SHORTCUT:
             y = self.conv2.fwd_short(a2, self.short, x, res2=res2, bias_sum=self.bsum, want_stats=want_stats)
         if y is None:
-            sc = self.short.fwd(x) if self.short is not None else x
+            if self.short is not None and not early:       # the one-launch form does not cover this shape after all
+                sc = self.short.fwd(x)
+            e.side_wait(1)
             y = self.conv2.fwd(a2, res=sc, res2=res2, want_stats=want_stats)
         if tape is not None:
             tape.append((self, (x, a1, coef1, h1, a2, coef2, mask, temb, training)))
@@ -539,10 +554,13 @@ class _ResBlock:
             if self.short is not None:
                 self.short.gb.copy_(self.conv2.gb)         # behind conv2's weight-gradient launch, wherever that runs
                 self.short._wgrad(dy, x, False, None)
-        da2 = self.conv2.dgrad(dy, h1.shape)
         dxs = dy
-        if self.short is not None:
-            dxs = self.short.dgrad(dy, x.shape) if need_dx else None
+        if self.short is not None and need_dx:                 # beside conv2's input gradient; needed by bn1's backward
+            with e.side_section(dy, lane=1):
+                dxs = self.short.dgrad(dy, x.shape)
+        elif self.short is not None:
+            dxs = None
+        da2 = self.conv2.dgrad(dy, h1.shape)
         # d(projected temb)[b][c] = sum over pixels of dh1; conv1 bias gradient = its sum over b: both
         # come out of the BatchNorm backward's statistics pass (dh1 is affine in the summed terms)
         if self.temb is not None:
@@ -568,6 +586,7 @@ class _ResBlock:
         else:
             self.conv1.wgrad(dh1, a1, bias=not training)
         da1 = self.conv1.dgrad(dh1, x.shape)
+        e.side_wait(1)
         return self.bn1.bwd(da1, x, coef1, None, add=dxs, add2=extra, need_dx=need_dx, training=training)
 
 
@@ -818,6 +837,7 @@ class Engine:
         # zero-filled once, then owned by the kernels (flags and partial sums of tiles split between workgroups)
         # (partial products of layers whose reduction is split between workgroups: the small, deep layers)
         self.scratch = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=self.device)
+        self.scratch_aux = torch.zeros(_lib.CONV_SCRATCH_BYTES, dtype=torch.uint8, device=self.device)   # the shortcuts'
         self.dt = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}[dtype]
 
         # one flat fp32 arena for parameters and one for gradients; every nn.Parameter becomes a view
@@ -868,7 +888,7 @@ class Engine:
         self.drop_generator = None
         self.profile = None               # list -> receives (kind, flops, start, end) per MFMA conv launch
         self.side_wgrad = SIDE_WGRAD        # weight gradients of backward on a second stream (see SIDE_WGRAD)
-        self._side_stream, self._side_on, self._side_keep = None, False, []
+        self._side_streams, self._side_raw, self._side_used, self._side_on, self._side_keep = None, None, [False, False], False, []
         self.debug_taps = None            # dict -> receives (output, folded skip) per layer (diagnostics)
         self._tproj_cache, self.tproj_for, self.tproj_src = {}, {}, None
         self._tbwd_cache, self.tbwd_for = {}, {}
@@ -1047,6 +1067,7 @@ class Engine:
         self.act_for.clear()
         if training:
             self.coef_epoch += 1                              # running statistics are about to change
+        self._side_begin(x.device)                            # the blocks' 1x1 shortcuts run beside their first convolution
         B = x.shape[0]
         drop_masks = drop_masks or {}
         emb = torch.empty((B, self.plan.ch), dtype=torch.float32, device=x.device)
@@ -1083,27 +1104,29 @@ class Engine:
         out = self.end.fwd(h)
         if tape is not None:
             tape.append(("end", (h,)))
+        self._side_join()
         return out
 
     @contextlib.contextmanager
-    def side_section(self, *tensors, torch_ops=False):
-        """Inside backward with the second stream on: the library launches of the block go to that stream, behind everything
-        the main stream has been given so far.  `tensors` (what the block reads) and whatever the block passes to
-        side_keep() (workspaces it allocates: they come from the main stream's pool) stay referenced until the streams are
-        joined, so the allocator cannot hand their memory to a later main-stream tensor.  torch_ops: the block calls torch
-        operators or collectives, so torch's current stream is switched too (a few microseconds of host time more).
-        Otherwise a no-op."""
+    def side_section(self, *tensors, torch_ops=False, lane=0):
+        """With the extra streams on (inside forward and backward): the library launches of the block go to stream `lane`
+        (0: backward's weight gradients, joined when backward returns; 1: the 1x1 shortcut convolutions, which main waits
+        for at side_wait(1)), behind everything the main stream has been given so far.  `tensors` (what the block reads)
+        and whatever the block passes to side_keep() (workspaces it allocates: they come from the main stream's pool) stay
+        referenced until the streams are joined, so the allocator cannot hand their memory to a later main-stream tensor.
+        torch_ops: the block calls torch operators or collectives, so torch's current stream is switched too (a few
+        microseconds of host time more).  Otherwise a no-op."""
         if not self._side_on:
             yield
             return
-        side = self._side_stream
-        call("vamd_stream_wait", self._side_raw, _raw_stream(_cur_device()))
+        call("vamd_stream_wait", self._side_raw[lane], _raw_stream(_cur_device()))
+        self._side_used[lane] = True
         self._side_keep.extend(tensors)
         if torch_ops:
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(self._side_streams[lane]):
                 yield
             return
-        _override.raw = self._side_raw
+        _override.raw = self._side_raw[lane]
         try:
             yield
         finally:
@@ -1113,15 +1136,22 @@ class Engine:
         if self._side_on and t is not None:
             self._side_keep.append(t)
 
+    def side_wait(self, lane):
+        """The main stream waits for what stream `lane` has been given so far (a result computed there is needed now)."""
+        if self._side_on and self._side_used[lane]:
+            call("vamd_stream_wait", _raw_stream(_cur_device()), self._side_raw[lane])
+            self._side_used[lane] = False
+
     def _side_begin(self, device):
         self._side_on = bool(self.side_wgrad) and device.type == "cuda"
-        if self._side_on and self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=device)
-            self._side_raw = self._side_stream.cuda_stream
+        if self._side_on and self._side_streams is None:
+            self._side_streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+            self._side_raw = [st.cuda_stream for st in self._side_streams]
 
     def _side_join(self):
         if self._side_on:
-            call("vamd_stream_wait", _raw_stream(_cur_device()), self._side_raw)
+            for lane in (0, 1):
+                self.side_wait(lane)
             self._side_on = False
         self._side_keep.clear()
 
