@@ -302,10 +302,14 @@ def main():
 
     stepper = None
 
+    ahead = getattr(model, "encode_ahead", None)      # latent diffusion: the next batch's first-stage encoding starts now,
+                                                      # as vision_amd.trainer's loop does (it runs beside this step)
     def step(i):
         dp.broadcast_buffers()
         if stepper is not None:
             return stepper(batches[i % nbatch], i)
+        if ahead is not None:
+            ahead(batches[(i + 1) % nbatch])
         loss = model.training_step(batches[i % nbatch], i)
         loss.backward()
         opt.step()

@@ -232,6 +232,49 @@ def test_latent_diffusion_over_the_first_stage():
     assert (m.last_codes.view(-1) == d.argmin(1)).float().mean().item() >= 0.98
 
 
+def test_first_stage_encoding_started_ahead_changes_nothing():
+    """LatentDiffusion.encode_ahead(next batch) while the current step runs (what the trainer's loop and bench.py do)
+    against steps that encode their own batch: identical losses and parameters after four optimiser steps; a batch that
+    was announced is encoded once, one that was not is encoded by its step; latent batches are left alone."""
+    from vision_amd.trainer import _with_lookahead
+    fs_cfg = dict(name="vqvaeunet", learning_rate=1e-3, manual_seed=42, h_dims=[3, 32, 64, 64], down_index=[0, 1, 1, 1],
+                  patch_size=32, sampling_period=1, embed_dim=64, num_embed=128, attn_res=[4], weight_decay=1e-3,
+                  scheduler_gamma=0.99)
+    ldm_cfg = dict(name="ldm", learning_rate=1e-3, manual_seed=42, h_dims=[64, 64, 64], down_index=[0, 0, 0], attn_res=[4],
+                   in_res=4, with_conv=True, dropout=0.1, diffusion_steps=4, sampling_period=1, grid=2, weight_decay=1e-5,
+                   scheduler_gamma=0.99)
+    gen = torch.Generator().manual_seed(2)
+    batches = [(torch.rand((4, 3, 32, 32), generator=gen).to(DEV), None) for _ in range(4)]
+    out = []
+    for ahead in (True, False):
+        torch.manual_seed(42)
+        fs = vision_amd.get_model("vqvaeunet", fs_cfg).to(DEV).eval()
+        torch.manual_seed(43)
+        m = vision_amd.get_model("ldm", ldm_cfg).to(DEV).train()
+        m.set_first_stage(fs)
+        opt = m.configure_optimizers()[0][0]
+        calls = []
+        plain = m.encode_images
+        m.encode_images = lambda x: (calls.append(id(x)), plain(x))[1]
+        torch.manual_seed(11)
+        torch.cuda.manual_seed(11)
+        losses = []
+        for i, b in enumerate(_with_lookahead(batches, m.encode_ahead if ahead else None)):
+            loss = m.training_step(b, i)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        assert calls == [id(b[0]) for b in ([batches[1], batches[0], batches[2], batches[3]] if ahead else batches)]
+        assert not m._ahead
+        out.append((torch.stack(losses).cpu(), m._ensure_engine().flat_p.clone()))
+    (l0, p0), (l1, p1) = out
+    assert torch.equal(l0, l1) and torch.equal(p0, p1)
+    z = torch.randn((4, 64, 4, 4), device=DEV)
+    m.encode_ahead((z, None))                                  # latents: nothing to encode
+    assert not m._ahead
+
+
 def test_run_flow_of_latent_diffusion(tmp_path, capsys):
     """run.py with `name: ldm` and a `first_stage_config`: image batches from the data module, latents from the (here
     untrained) first stage, metrics, decoded sample grids, a checkpoint that holds the latent UNet's keys only."""

@@ -100,6 +100,7 @@ class LatentDiffusion(DDPMModel):
         self.grad_reducer = None
         self.curr_device = None
         object.__setattr__(self, "_first_stage", None)       # not a submodule: its weights are not this model's
+        self._ahead, self._enc_stream = {}, None             # encodings started by encode_ahead(): id(images) -> (images, latents, event)
 
     # ------------------------------------------------------------------ engine plumbing
     def _ensure_engine(self) -> LatentEngine:
@@ -167,10 +168,36 @@ class LatentDiffusion(DDPMModel):
         finally:
             fs.train(was)
 
+    def encode_ahead(self, batch):
+        """Start the (frozen, eval-mode) first-stage encoding of an image batch a later step method will be given, on a
+        stream of its own: the encoder's full-resolution convolutions then run beside the current step's latent-UNet
+        kernels, most of which do not fill the chip.  The step method that receives the same image tensor takes the
+        result instead of encoding again.  A no-op for latent batches, without a first stage, and on the CPU."""
+        x_0 = batch[0]
+        if self._first_stage is None or x_0.shape[1] == self.h_dims[0] or not x_0.is_cuda or id(x_0) in self._ahead:
+            return
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=x_0.device)
+        enc = self._enc_stream
+        enc.wait_stream(torch.cuda.current_stream())              # the batch itself may still be on its way
+        with torch.cuda.stream(enc):
+            z = self.encode_images(x_0)
+            done = torch.cuda.Event()
+            done.record(enc)
+        while len(self._ahead) >= 2:                              # batches announced and never used
+            self._ahead.pop(next(iter(self._ahead)))
+        self._ahead[id(x_0)] = (x_0, z, done)
+
     def _latents_of(self, batch):
         x_0, _ = batch
         self.curr_device = x_0.device
         if self._first_stage is not None and x_0.shape[1] != self.h_dims[0]:
+            got = self._ahead.pop(id(x_0), None)
+            if got is not None and got[0] is x_0:
+                cur = torch.cuda.current_stream()
+                cur.wait_event(got[2])
+                got[1].record_stream(cur)                         # allocated on the encoder's stream, read on this one
+                return got[1]
             return self.encode_images(x_0)
         return x_0
 

@@ -179,6 +179,24 @@ class ImageFolderDataModule:
         return self._loader("test", False)
 
 
+def _with_lookahead(loader, announce):
+    """The loader's batches, each yielded after `announce(next batch)` has been called (a model that prepares part of a
+    step ahead of time, LatentDiffusion.encode_ahead); announce=None: the loader as it is."""
+    if announce is None:
+        yield from loader
+        return
+    it = iter(loader)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        announce(nxt)
+        yield cur
+        cur = nxt
+    yield cur
+
+
 class Trainer:
     """fit / test loops with the handful of `pl.Trainer` arguments the reference's YAMLs use
     (accelerator, devices, max_epochs, precision) plus max_steps / limit_* for smoke runs."""
@@ -270,7 +288,8 @@ class Trainer:
             if hasattr(datamodule, "epoch"):
                 datamodule.epoch = epoch
             model.train()
-            for i, batch in enumerate(datamodule.train_dataloader(self.global_rank, self.world_size)):
+            for i, batch in enumerate(_with_lookahead(datamodule.train_dataloader(self.global_rank, self.world_size),
+                                                      getattr(model, "encode_ahead", None))):
                 if self.dp is not None:
                     self.dp.broadcast_buffers()
                 shape = tuple(batch[0].shape)
