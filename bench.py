@@ -443,6 +443,7 @@ def main():
                 str(shape), n, t / n, f / (t * 1e-3) / 1e12, 100 * t / sum(v[1] for v in per_shape.values())), file=sys.stderr)
     extra["mfma_conv_ms_per_step"] = round(conv_ms / n_inst, 3)
     extra["ms_per_step_with_launch_events"] = round(inst_ms, 3)
+    extra["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)      # torch's allocator, training steps only so far
     extra["weight_gradient_stream"] = two_streams
     if one_stream_ms is not None:
         extra["ms_per_step_one_stream"] = round(one_stream_ms, 3)
