@@ -27,6 +27,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 static __device__ __attribute__((aligned(256))) unsigned char t_zero_page[256];
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 #define TGPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define TLPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -42,17 +43,25 @@ __device__ __forceinline__ bf16x8_t zero8() {
 // The filter fragments and the per-channel epilogue constants stay in registers across the tiles.
 constexpr int kThinInTiles = 4;
 
+__host__ __device__ constexpr int thin_in_halo_bytes(int HT, int Cin) { return (HT * HT * Cin * 2 + 15) / 16 * 16; }
+
 template <int K, int NTN>
 __global__ void __launch_bounds__(256)
 thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                     const float* __restrict__ bias, const float* __restrict__ temb,
                     const bf16_t* __restrict__ res, const bf16_t* __restrict__ res2, bf16_t* __restrict__ y,
-                    int tiles_w, int tiles_h, int ntiles) {
+                    int tiles_w, int tiles_h, int ntiles, int nt_store) {
     constexpr int HT = 16 + K - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);          // [HT][HT][Cin], zero outside the image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Cin = g.Cin, Ktot = K * K * Cin, Cout = 16 * NTN;
+    // 64 output channels: a pixel is one 128-byte line, of which a lane holds 32 bytes.  A tile row's 16 pixels pass through
+    // 2 KB of LDS owned by the wave (row = pixel, 16-byte chunk index XOR ((pixel >> 1) & 7): conflict-free both ways) and
+    // lane L then stores chunk L & 7 of pixel 8 h + (L >> 3): whole lines per store instead of sixteen quarter lines, and
+    // non-temporal for a large output (224 x 224 x 64 images: 126 -> 89 us, 1024 x 1024 x 4: 170 -> 107 us)
+    constexpr bool XP = NTN == 4;
+    const uint32_t xp_base = (uint32_t)(uintptr_t)TLPTR(smem_raw + thin_in_halo_bytes(HT, g.Cin)) + (uint32_t)wave * 2048u;
 
     // A = filter, rows permuted: MFMA jt, row i  <->  output channel (i>>2)*(4*NTN) + 4*jt + (i&3),
     // so that the 4*NTN accumulators of a lane are consecutive channels
@@ -174,7 +183,31 @@ thin_in_mfma_kernel(ConvGeom g, const bf16_t* __restrict__ x, const bf16_t* __re
                     Vec16<bf16_t> ov;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ov.v[e] = from_f<bf16_t>(v[e]);
-                    *reinterpret_cast<Vec16<bf16_t>*>(y + m * Cout + cc) = ov;
+                    if constexpr (XP) {
+                        const uint32_t wa = xp_base + (uint32_t)p * 128u + (uint32_t)(((2 * grp + ch) ^ ((p >> 1) & 7)) << 4);
+                        asm volatile("ds_write_b128 %0, %1" ::"v"(wa), "v"(__builtin_bit_cast(u32x4_t, ov)) : "memory");
+                    } else {
+                        *reinterpret_cast<Vec16<bf16_t>*>(y + m * Cout + cc) = ov;
+                    }
+                }
+            }
+            if constexpr (XP) {                               // every lane: pixels past the image edge are skipped below
+                const int64_t m0 = ((int64_t)b * g.H + h) * g.W + w0;
+                u32x4_t o0, o1;
+                const uint32_t ra0 = xp_base + (uint32_t)(lane >> 3) * 128u + (uint32_t)(((lane & 7) ^ ((lane >> 4) & 7)) << 4);
+                const uint32_t ra1 = xp_base + (uint32_t)(8 + (lane >> 3)) * 128u + (uint32_t)(((lane & 7) ^ ((4 + (lane >> 4)) & 7)) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(ra0) : "memory");
+                asm volatile("ds_read_b128 %0, %1" : "=v"(o1) : "v"(ra1) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1)::"memory");
+                const int px = lane >> 3;
+                u32x4_t* d0 = reinterpret_cast<u32x4_t*>(y + (m0 + px) * Cout + (lane & 7) * 8);
+                u32x4_t* d1 = reinterpret_cast<u32x4_t*>(y + (m0 + px + 8) * Cout + (lane & 7) * 8);
+                if (nt_store) {
+                    if (w0 + px < g.W) __builtin_nontemporal_store(o0, d0);
+                    if (w0 + px + 8 < g.W) __builtin_nontemporal_store(o1, d1);
+                } else {
+                    if (w0 + px < g.W) *d0 = o0;
+                    if (w0 + px + 8 < g.W) *d1 = o1;
                 }
             }
         }
@@ -557,11 +590,13 @@ static void launch_thin_in(const ConvGeom& g, const void* x, const void* w, cons
                            const void* res, const void* res2, void* y, hipStream_t st) {
     const int tw = (g.W + 15) / 16, th = (g.H + 15) / 16;
     constexpr int HT = 16 + K - 1;
-    const size_t lds = (size_t)HT * HT * g.Cin * 2;
+    const size_t lds = (size_t)thin_in_halo_bytes(HT, g.Cin) + (NTN == 4 ? 4 * 2048 : 0);   // + the waves' transposing regions
     const int ntiles = g.B * th * tw;
+    // non-temporal stores from 40 MB of output on: a smaller one the next kernel finds in the caches
+    const int nt_store = (int64_t)g.B * g.H * g.W * g.Cout * 2 >= (40ll << 20);
     hipLaunchKernelGGL((thin_in_mfma_kernel<K, NTN>), dim3((unsigned)((ntiles + kThinInTiles - 1) / kThinInTiles)), dim3(256),
                        lds, st, g, (const bf16_t*)x, (const bf16_t*)w, bias, temb, (const bf16_t*)res,
-                       (const bf16_t*)res2, (bf16_t*)y, tw, th, ntiles);
+                       (const bf16_t*)res2, (bf16_t*)y, tw, th, ntiles, nt_store);
 }
 
 int thin_in_mfma(const ConvGeom& g, const void* x, const void* w, const float* bias, const float* temb,
