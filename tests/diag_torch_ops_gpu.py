@@ -35,3 +35,19 @@ rows = [e for e in prof.key_averages() if e.key.startswith("aten::") and e.devic
 rows.sort(key=lambda e: -e.count)
 for e in rows[:25]:
     print(f"{e.key:40s} calls/step {e.count / 3:6.1f}  device us/step {e.device_time_total / 3:8.1f}")
+print("-- memory copies and fills (any origin)")
+for e in sorted(prof.key_averages(), key=lambda e: -e.count):
+    if "emcpy" in e.key or "emset" in e.key or "copyBuffer" in e.key or "fillBuffer" in e.key:
+        print(f"{e.key[:70]:70s} calls/step {e.count / 3:6.1f}  device us/step {e.device_time_total / 3:8.1f}")
+print("-- host-side ops that contain them")
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof2:
+    step(7)
+    torch.cuda.synchronize()
+seen = {}
+for ev in prof2.events():
+    if ev.name in ("hipMemcpyAsync", "hipMemcpyWithStream", "hipMemcpyDtoDAsync", "hipMemsetAsync") or "emcpy" in ev.name:
+        st = [s for s in (ev.stack or []) if "vision_amd" in s or "bench" in s or "tests/" in s]
+        key = (ev.name, st[0] if st else "?")
+        seen[key] = seen.get(key, 0) + 1
+for (n, where), c in sorted(seen.items(), key=lambda kv: -kv[1])[:20]:
+    print(f"{c:4d} x {n:24s} {where}")

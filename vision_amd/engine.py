@@ -1166,8 +1166,9 @@ class Engine:
         self._side_begin(dout.device)
         self.end.wgrad(dout, h_end)
         g = self.end.dgrad(dout, h_end.shape)
-        if red is not None:
-            with self.side_section(torch_ops=True):   # a bucket goes out behind both streams' work so far
+        live = red is not None and getattr(red, "_on", True)      # ranks to exchange with: a bucket goes out behind both
+        if red is not None:                                        # streams' work so far (else the call only keeps count)
+            with self.side_section(torch_ops=True) if live else contextlib.nullcontext():
                 red.layer_done(self._lows["End"])
         nd, nm = self.n_down, self.n_mid
         n_up = len(self.layers) - nd - nm
@@ -1190,7 +1191,7 @@ class Engine:
                 dskip[nd - 1 - j] = g_in
             g = g_in
             if red is not None and self._lows[layer.spec.prefix] is not None:
-                with self.side_section(torch_ops=True):
+                with self.side_section(torch_ops=True) if live else contextlib.nullcontext():
                     red.layer_done(self._lows[layer.spec.prefix])
         tag, (emb, t1, temb) = tape.pop()
         assert tag == "temb"
@@ -1200,7 +1201,7 @@ class Engine:
         self.lin2.bwd(t1, dtemb, dx=dt1)
         self.lin1.bwd(emb, dt1, dx=None)
         if red is not None:
-            with self.side_section(torch_ops=True):
+            with self.side_section(torch_ops=True) if live else contextlib.nullcontext():
                 red.finish()
         self._side_join()
         self.attach_grads()

@@ -11,6 +11,8 @@ objects, arenas and weight re-packing, with the first stage's own wiring:
 """
 from typing import Dict, List, Optional
 
+import contextlib
+
 import torch
 
 from ._lib import BF16, F32, call, lib
@@ -159,8 +161,9 @@ class VQUNetEngine(Engine):
         self._side_begin(dout.device)                 # weight gradients on the second stream, as in Engine.backward
         self.end.wgrad(dout, h_end)
         g = self.end.dgrad(dout, h_end.shape)
+        live = red is not None and getattr(red, "_on", True)
         if red is not None:
-            with self.side_section(torch_ops=True):
+            with self.side_section(torch_ops=True) if live else contextlib.nullcontext():
                 red.layer_done(self._lows["End"])
         ne, n = self.n_enc, len(self.layers)
         dskip: Dict[int, torch.Tensor] = {}
@@ -174,12 +177,12 @@ class VQUNetEngine(Engine):
             if 0 <= j < ne:
                 dskip[ne - 1 - j] = g                   # the decoder input was a sum: its gradient reaches the skip too
             if red is not None and self._lows[layer.spec.prefix] is not None:
-                with self.side_section(torch_ops=True):
+                with self.side_section(torch_ops=True) if live else contextlib.nullcontext():
                     red.layer_done(self._lows[layer.spec.prefix])
             if i == ne:
                 g = self._quantize_bwd(tape, g, dskip.pop(ne - 1), g_vq)
         if red is not None:
-            with self.side_section(torch_ops=True):
+            with self.side_section(torch_ops=True) if live else contextlib.nullcontext():
                 red.finish()
         self._side_join()
         self.attach_grads()
