@@ -265,3 +265,17 @@ def test_cpu_baseline_reports_its_sample():
     out = bench.cpu_baseline(seconds_budget=0.5)           # one step here; the default budget covers the 20 the config names
     assert out["kind"] == "port" and out["unit"] == "images/s" and out["steps"] >= 1 and out["batch"] == 8
     assert out["value"] > 0 and out["cores"] >= 1 and "training steps" in out["sample"]
+
+
+def test_loader_lookahead_announces_each_next_batch_once():
+    """vision_amd.trainer._with_lookahead: every batch is yielded once and in order; before batch i is yielded, batch i + 1
+    (if there is one) has been announced exactly once; without an announcer the loader is passed through."""
+    from vision_amd.trainer import _with_lookahead
+    seen = []
+    out = []
+    for b in _with_lookahead(iter(range(5)), seen.append):
+        out.append((b, list(seen)))
+    assert [b for b, _ in out] == [0, 1, 2, 3, 4]
+    assert [s for _, s in out] == [[1], [1, 2], [1, 2, 3], [1, 2, 3, 4], [1, 2, 3, 4]]
+    assert list(_with_lookahead(iter([]), seen.append)) == [] and seen == [1, 2, 3, 4]
+    assert list(_with_lookahead([7, 8], None)) == [7, 8]
